@@ -249,3 +249,48 @@ class OracleVec:
         """Integer aux state per env: step, phase, mission_successful, success_run, hist_len."""
         return np.array([[e.step, e.phase, e.mission_successful, e.success_run, e.hist_len, e.has_prev_action]
                          for e in self.envs], dtype=np.int64)
+
+
+def load_export(vec, dyn, aux, prev_action, hist):
+    """Copy a tvc_env_export_state() snapshot (numpy arrays) into an OracleVec.
+    aux columns: step, phase, mission_successful, success_run, hist_len, has_prev_action, distinct, episode."""
+    L = lib()
+    W = hist.shape[1]
+    for i in range(vec.n):
+        e = vec.envs[i]
+        for k in range(3):
+            e.pos[k] = float(dyn[i, k])
+            e.vel[k] = float(dyn[i, 7 + k])
+            e.omega[k] = float(dyn[i, 10 + k])
+        for k in range(4):
+            e.quat[k] = float(dyn[i, 3 + k])
+        e.step = int(aux[i, 0])
+        e.phase = int(aux[i, 1])
+        e.mission_successful = int(aux[i, 2])
+        e.success_run = int(aux[i, 3])
+        e.has_prev_action = int(aux[i, 5])
+        e.prev_action[0] = float(prev_action[i, 0])
+        e.prev_action[1] = float(prev_action[i, 1])
+        e.fuel = L.tvc_oracle_fuel_after(int(aux[i, 0]))
+        hl = int(aux[i, 4])
+        wl = min(hl, W)
+        # the device keeps only the last W rewards; older entries (hl - wl of them) are unknown to it
+        # and only their count matters when distinct_window == W.
+        e.hist_head = 0
+        e.hist_len = hl
+        pad = hl - wl
+        for k in range(pad):
+            e.hist[k] = -12345.0 - k  # distinct fillers outside any window the oracle will look at
+        for k in range(wl):
+            e.hist[pad + k] = float(hist[i, k])
+
+
+def params_from_export(base_over, par_row):
+    """Per-env oracle params from one row of the exported DR params
+    (mass_scale, thrust_scale, cg_offset, wind xyz)."""
+    p = default_params(**base_over)
+    lib().tvc_oracle_scale_mass(C.byref(p), float(par_row[0]))
+    p.thrust = p.thrust * float(par_row[1])
+    p.cg_offset = float(par_row[2])
+    p.wind[0], p.wind[1], p.wind[2] = float(par_row[3]), float(par_row[4]), float(par_row[5])
+    return p

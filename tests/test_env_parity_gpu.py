@@ -1,0 +1,335 @@
+"""HIP integrator kernel (through the C ABI) vs the fp64 oracle on the same seeded inputs.
+
+Tolerances (stated here, used below):
+  * dynamic state / observation: |gpu - oracle| <= 1e-4 * max(1, |oracle|) per component over 100 steps
+    (north_star: <= 1e-4 rel over 100 steps; fp32 kernel vs fp64 oracle)
+  * reward: |gpu - oracle| <= 2e-3 * max(1, |oracle|)   (exp(-10*(tilt-0.087)) amplifies state error ~500x)
+  * terminated / truncated / phase / success: bit-exact, except for envs whose oracle-side derived
+    scalars sit within MARGIN of a threshold at that step (fp32 cannot resolve which side); such envs
+    are dropped from later comparisons because their trajectories legitimately fork there.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import envoracle as eo
+
+pytestmark = pytest.mark.gpu
+
+MARGIN = 2e-4
+TH_TILT = [0.087, 0.05, 0.1, 0.52]
+TH_ALT = [0.1, 0.2, 0.5, 1.0, 2.0, 5.0, 20.0]
+TH_W = [0.1, 0.2]
+
+
+def _near(x, ths, m=MARGIN):
+    x = np.asarray(x)[:, None]
+    return (np.abs(x - np.asarray(ths)[None, :]) <= m * np.maximum(1.0, np.abs(np.asarray(ths)))[None, :]).any(axis=1)
+
+
+def oracle_scalars(vec):
+    out = np.zeros((vec.n, 7))
+    for i in range(vec.n):
+        sc = eo.Scalars()
+        eo.lib().tvc_oracle_scalars_from_state(vec.envs[i], sc)
+        out[i] = [sc.altitude, sc.tilt, sc.omega_mag, sc.v_h, sc.v_z_abs, sc.x, sc.y]
+    return out
+
+
+def ambiguous(sc, actions, phases=None):
+    """Envs whose discrete outcome fp32 may legitimately decide differently at this step.
+    Altitude thresholds 5 / 1 / 0.5 only matter in the phase whose transition they gate (ref :646-654)."""
+    amb = _near(sc[:, 1], TH_TILT) | _near(sc[:, 0], [0.1, 0.2, 2.0, 20.0]) | _near(sc[:, 2], TH_W)
+    if phases is not None:
+        amb |= (phases == 1) & _near(sc[:, 0], [5.0])
+        amb |= (phases == 2) & _near(sc[:, 0], [1.0])
+        amb |= (phases == 3) & _near(sc[:, 0], [0.5])
+    else:
+        amb |= _near(sc[:, 0], [0.5, 1.0, 5.0])
+    amb |= _near(sc[:, 3], [0.5]) | _near(sc[:, 4], [2.0])
+    amb |= _near(np.hypot(sc[:, 5], sc[:, 6]), [50.0])
+    ce = np.hypot(np.clip(actions[:, 0], -1, 1), np.clip(actions[:, 1], -1, 1))
+    amb |= _near(ce, [0.5, 0.9])
+    return amb
+
+
+def make_env(n, **kw):
+    from tvc_ai_amd import VecRocketTVCEnv
+    return VecRocketTVCEnv(n, device="cuda:0", **kw)
+
+
+def random_flight_state(rng, n):
+    dyn = np.zeros((n, 13), dtype=np.float64)
+    dyn[:, 0:2] = rng.uniform(-5, 5, (n, 2))
+    dyn[:, 2] = rng.uniform(6.0, 15.0, n)
+    ang = rng.uniform(-0.15, 0.15, (n, 3))
+    th = np.linalg.norm(ang, axis=1) + 1e-12
+    dyn[:, 3:6] = ang / th[:, None] * np.sin(th / 2)[:, None]
+    dyn[:, 6] = np.cos(th / 2)
+    dyn[:, 7:10] = rng.normal(0, 1.0, (n, 3))
+    dyn[:, 10:13] = rng.normal(0, 0.3, (n, 3))
+    return dyn.astype(np.float32)
+
+
+def run_parity(env, vec, actions_seq, alive=None, rew_tol=2e-3, st_tol=1e-4, forks_ok=False, use_margins=True):
+    """Steps both sides on the same actions and compares every step: observation, reward, flags, the
+    dynamic state and the integer aux state (step, phase, success flag, success run length).
+
+    An env whose oracle-side scalars sit within MARGIN of a threshold is "ambiguous" at that step: its
+    reward may legitimately jump and its discrete state may legitimately differ; it is dropped only if the
+    discrete state actually differs (its trajectory forks there), otherwise it stays in the comparison.
+    forks_ok=True (ground contact): an impact with Coulomb friction is a discontinuous map (which substep
+    first touches, stick vs slip), so an fp32 and an fp64 run of the SAME model fork on a minority of envs;
+    those are dropped and counted when their state error first exceeds the tolerance."""
+    n = vec.n
+    alive = np.ones(n, bool) if alive is None else alive
+    worst = dict(obs=0.0, rew=0.0, dyn=0.0, forks=0, amb_drops=0, med=0.0)
+    for t, act in enumerate(actions_seq):
+        phases_before = np.array([e.phase for e in vec.envs])
+        a_t = torch.from_numpy(act.astype(np.float32)).cuda()
+        obs, rew, term, trunc, _ = env.step(a_t)
+        o_obs, o_rew, o_term, o_trunc = vec.step(act.astype(np.float32).astype(np.float64))
+        g_obs, g_rew = obs.cpu().numpy(), rew.cpu().numpy()
+        g_term, g_trunc = term.cpu().numpy(), trunc.cpu().numpy()
+        st = env.export_state()
+        g_dyn = st["dyn"].cpu().numpy().astype(np.float64)
+        g_aux = st["aux"].cpu().numpy()[:, :4]
+        o_dyn = vec.state13()
+        o_aux = vec.aux()[:, :4]
+        amb = ambiguous(vec._last_sc, act, phases_before) if use_margins else np.zeros(n, bool)
+        ed = (np.abs(g_dyn - o_dyn) / np.maximum(1.0, np.abs(o_dyn))).max(axis=1)
+        eo_ = (np.abs(g_obs - o_obs) / np.maximum(1.0, np.abs(o_obs))).max(axis=1)
+        er = np.abs(g_rew - o_rew) / np.maximum(1.0, np.abs(o_rew))
+        if forks_ok:
+            forked = alive & (ed > st_tol)
+            worst["forks"] += int(forked.sum())
+            alive &= ~forked
+        disc_diff = (g_term != o_term) | (g_trunc != o_trunc) | (g_aux != o_aux).any(axis=1)
+        bad = disc_diff & alive & ~amb
+        assert not bad.any(), (f"step {t}: discrete state mismatch away from thresholds, envs {np.nonzero(bad)[0][:8]} "
+                               f"gpu {g_aux[bad][:4].tolist()} oracle {o_aux[bad][:4].tolist()}")
+        worst["amb_drops"] += int((disc_diff & alive).sum())
+        alive &= ~disc_diff
+        if not alive.any():
+            break
+        worst["dyn"] = max(worst["dyn"], ed[alive].max())
+        worst["obs"] = max(worst["obs"], eo_[alive].max())
+        worst["med"] = max(worst["med"], float(np.median(ed[alive])))
+        assert ed[alive].max() <= st_tol, f"step {t}: state err {ed[alive].max()}"
+        assert eo_[alive].max() <= st_tol, f"step {t}: obs err {eo_[alive].max()}"
+        chk = alive & ~amb
+        if chk.any():
+            worst["rew"] = max(worst["rew"], er[chk].max())
+            assert er[chk].max() <= rew_tol, f"step {t}: reward err {er[chk].max()} env {np.argmax(er * chk)}"
+    return worst, alive
+
+
+class ScVec(eo.OracleVec):
+    """OracleVec that also records the post-physics derived scalars of the step (for margins)."""
+
+    def step(self, actions):
+        import ctypes as C
+        actions = np.asarray(actions, dtype=np.float64)
+        n = self.n
+        obs = np.zeros((n, 10), np.float32)
+        rew = np.zeros(n)
+        term = np.zeros(n, np.uint8)
+        trunc = np.zeros(n, np.uint8)
+        self._last_sc = np.zeros((n, 7))
+        out = eo.Out()
+        a = (C.c_double * 2)()
+        for i in range(n):
+            a[0], a[1] = actions[i]
+            eo.lib().tvc_oracle_step(C.byref(self.envs[i]), C.byref(self._p(i)), a, C.byref(out))
+            obs[i] = np.frombuffer(out.obs, dtype=np.float32)
+            rew[i], term[i], trunc[i] = out.reward, out.terminated, out.truncated
+            s = out.sc
+            self._last_sc[i] = [s.altitude, s.tilt, s.omega_mag, s.v_h, s.v_z_abs, s.x, s.y]
+        return obs, rew, term, trunc
+
+
+def test_reset_observation():
+    env = make_env(100)
+    obs, _ = env.reset()
+    ref = eo.OracleEnv().observe()
+    np.testing.assert_array_equal(obs.cpu().numpy(), np.tile(ref, (100, 1)))
+    st = env.export_state()
+    aux = st["aux"].cpu().numpy()
+    assert (aux[:, :7] == 0).all() and (aux[:, 7] == 1).all()  # episode counter: one soft reset so far
+    env.close()
+
+
+def test_free_flight_100_steps_random_init():
+    """<= 1e-4 relative over 100 steps on identical inputs (north_star), N not a multiple of 64."""
+    n = 333
+    rng = np.random.default_rng(7)
+    env = make_env(n, contact=0, auto_reset=0)
+    env.reset()
+    dyn0 = random_flight_state(rng, n)
+    env.import_state(dyn=dyn0)
+    vec = ScVec(n, contact=0, auto_reset=0, distinct_window=10)
+    vec.set_state13(dyn0.astype(np.float64))
+    acts = rng.uniform(-1.2, 1.2, (100, n, 2))
+    worst, alive = run_parity(env, vec, acts)
+    print("free-flight worst rel err:", worst, "alive", alive.sum(), "/", n)
+    assert alive.sum() > 0.5 * n
+    env.close()
+
+
+def test_nominal_zero_action_with_contact():
+    """The shipped scenario: zero action from the nominal pose; ground contact from step ~34 on."""
+    n = 64
+    env = make_env(n, contact=1, auto_reset=0)
+    env.reset()
+    vec = ScVec(n, contact=1, auto_reset=0, distinct_window=10)
+    acts = np.zeros((260, n, 2))
+    worst, alive = run_parity(env, vec, acts, st_tol=2e-4, use_margins=False)
+    print("nominal+contact worst:", worst, "alive", alive.sum())
+    assert alive.all()
+    aux = env.export_state()["aux"].cpu().numpy()
+    assert (aux[:, 0] == 260).all()
+    env.close()
+
+
+def test_auto_reset_random_actions_with_contact():
+    n = 512
+    rng = np.random.default_rng(11)
+    env = make_env(n, contact=1, auto_reset=1)
+    env.reset()
+    vec = ScVec(n, contact=1, auto_reset=1, distinct_window=10)
+    acts = rng.uniform(-0.3, 0.3, (200, n, 2))
+    worst, alive = run_parity(env, vec, acts, st_tol=5e-4, rew_tol=5e-3, forks_ok=True)
+    print("auto-reset+contact worst:", worst, "alive", alive.sum(), "/", n)
+    assert alive.sum() > 0.6 * n and worst["forks"] < 0.2 * n and worst["med"] < 5e-5
+    epi = env.export_state()["aux"].cpu().numpy()[:, 7]
+    assert epi.max() >= 1  # episodes did end and restart
+    env.close()
+
+
+def test_exact_distinct_window_mode():
+    """distinct_window=1000 (reference-exact anti-hacking) incl. repeated clipped rewards."""
+    n = 70
+    rng = np.random.default_rng(3)
+    env = make_env(n, contact=0, auto_reset=1, distinct_window=1000)
+    env.reset()
+    vec = ScVec(n, contact=0, auto_reset=1, distinct_window=1000)
+    acts = rng.uniform(-1, 1, (150, n, 2))
+    worst, alive = run_parity(env, vec, acts)
+    print("exact-window worst:", worst, "alive", alive.sum(), "/", n)
+    st = env.export_state()
+    aux = st["aux"].cpu().numpy()
+    hist = st["hist"].cpu().numpy()
+    for i in np.nonzero(alive)[0][:32]:
+        hl = aux[i, 4]
+        assert hl == 150
+        assert aux[i, 6] == len(set(hist[i, :hl].tolist())), "incremental distinct count drifted"
+    env.close()
+
+
+def test_domain_randomisation_parity():
+    n = 192
+    rng = np.random.default_rng(5)
+    over = dict(contact=1, auto_reset=0)
+    env = make_env(n, dr_enabled=1, dr_mass_var=0.3, dr_thrust_std=0.2, dr_cg_max=0.1, dr_wind_std=3.0,
+                   dr_init_tilt_max=0.05, seed=1234, **over)
+    env.reset()
+    st = env.export_state()
+    par = st["params"].cpu().numpy()
+    dyn = st["dyn"].cpu().numpy()
+    assert par[:, 0].min() >= 0.7 - 1e-6 and par[:, 0].max() <= 1.3 + 1e-6 and par[:, 0].std() > 0.1
+    assert par[:, 1].min() >= 0.5 and par[:, 1].max() <= 1.5 and 0.1 < par[:, 1].std() < 0.3
+    assert np.abs(par[:, 2]).max() <= 0.1 + 1e-6
+    assert 2.0 < par[:, 3].std() < 4.0 and 2.0 < par[:, 4].std() < 4.0 and (par[:, 5] == 0).all()
+    np.testing.assert_allclose(np.linalg.norm(dyn[:, 3:7], axis=1), 1.0, atol=1e-6)
+    vec = ScVec(n, distinct_window=10, **over)
+    vec.set_per_env_params([eo.params_from_export(dict(distinct_window=10, **over), par[i]) for i in range(n)])
+    vec.set_state13(dyn.astype(np.float64))
+    acts = rng.uniform(-0.5, 0.5, (100, n, 2))
+    worst, alive = run_parity(env, vec, acts, st_tol=5e-4, rew_tol=5e-3, forks_ok=True)
+    print("DR worst:", worst, "alive", alive.sum(), "/", n)
+    assert alive.sum() > 0.5 * n and worst["forks"] < 0.2 * n and worst["med"] < 5e-5
+    # same seed / ids -> same draws, whatever the sharding (rank-independence)
+    env2 = make_env(n // 2, dr_enabled=1, dr_mass_var=0.3, dr_thrust_std=0.2, dr_cg_max=0.1, dr_wind_std=3.0,
+                    dr_init_tilt_max=0.05, seed=1234, env_id_offset=n // 2, **over)
+    env2.reset()
+    par2 = env2.export_state()["params"].cpu().numpy()
+    np.testing.assert_array_equal(par2, par[n // 2:])
+    env.close()
+    env2.close()
+
+
+def test_step_many_equals_repeated_step():
+    n, T = 200, 37
+    rng = np.random.default_rng(9)
+    acts = torch.from_numpy(rng.uniform(-1, 1, (T, n, 2)).astype(np.float32)).cuda()
+    e1 = make_env(n)
+    e2 = make_env(n)
+    e1.reset()
+    e2.reset()
+    obs_m, rew_m, term_m, trunc_m = e1.step_many(acts)
+    for t in range(T):
+        o, r, te, tr, _ = e2.step(acts[t])
+        assert torch.equal(o, obs_m[t]) and torch.equal(r, rew_m[t])
+        assert torch.equal(te, term_m[t]) and torch.equal(tr, trunc_m[t])
+    s1, s2 = e1.export_state(), e2.export_state()
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k
+    e1.close()
+    e2.close()
+
+
+def test_full_size_properties():
+    """BASELINE sizes (65 536 envs): size-independent invariants instead of an oracle replay."""
+    n = 65536
+    env = make_env(n, want_final_obs=True)
+    obs0, _ = env.reset()
+    first = obs0[0].clone()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    ep_done = torch.zeros(n, dtype=torch.int64, device="cuda")
+    for t in range(120):
+        a = torch.rand((n, 2), device="cuda", generator=g) * 2 - 1
+        obs, rew, term, trunc, info = env.step(a)
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+        qn = obs[:, :4].norm(dim=1)
+        assert (qn - 1).abs().max() < 1e-5
+        assert rew.max() <= 200.0 and rew.min() >= -1000.0
+        done = (term | trunc).bool()
+        ep_done += done
+        if done.any():  # auto-reset rows carry the reset observation, final_observation the terminal one
+            assert torch.equal(obs[done], first.expand(int(done.sum()), -1))
+            assert (info["final_observation"][done][:, 9] > 0).all()
+        assert torch.equal(info["final_observation"][~done], obs[~done])
+    assert ep_done.sum() > n  # random actions tip the rocket over within ~50 steps
+    # identical envs fed identical actions stay bit-identical (determinism across lanes / blocks)
+    env.reset(hard=True)
+    a = torch.rand((1, 2), device="cuda", generator=g).expand(n, 2).contiguous() * 0.2
+    for _ in range(50):
+        obs, rew, *_ = env.step(a)
+    assert torch.equal(obs, obs[:1].expand(n, -1)) and torch.equal(rew, rew[:1].expand(n))
+    env.close()
+
+
+def test_reference_surface_n1():
+    """EnhancedRocketTVCEnv wrapper: reference return types and info keys (scripts/train.py:565-616)."""
+    from tvc_ai_amd import EnhancedRocketTVCEnv
+    env = EnhancedRocketTVCEnv(enable_curiosity=False)
+    obs, info = env.reset()
+    assert obs.shape == (10,) and obs.dtype == np.float32
+    oenv = eo.OracleEnv(contact=1, distinct_window=1000)
+    total = 0.0
+    for t in range(60):
+        a = env.action_space.sample() * 0.2
+        obs, reward, terminated, truncated, info = env.step(a)
+        o = oenv.step(a.astype(np.float64))
+        assert isinstance(reward, float) and isinstance(terminated, bool) and isinstance(truncated, bool)
+        for k in ("mission_successful", "tilt_angle_deg", "angular_velocity_mag", "altitude", "mission_phase",
+                  "fuel_remaining", "position", "step"):
+            assert k in info
+        np.testing.assert_allclose(obs, np.frombuffer(o.obs, dtype=np.float32), rtol=1e-4, atol=1e-4)
+        assert abs(reward - o.reward) <= 5e-3 * max(1.0, abs(o.reward))
+        assert terminated == bool(o.terminated) and truncated == bool(o.truncated)
+        assert abs(info["altitude"] - o.sc.altitude) < 1e-3
+        total += reward
+        if terminated or truncated:
+            break
+    env.close()

@@ -1,0 +1,96 @@
+"""ctypes loader for libtvc_hip.so (the C ABI declared in include/tvc_native.h).
+
+There is no CPU fallback: if the library is missing it is built with hipcc; if it cannot be
+loaded, or no GPU is visible when a handle is created, the product path raises.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loaded first so that libamdhip64.so.7 resolves to the copy torch ships)
+
+from . import build as _build
+
+_lib = None
+
+
+class TvcError(RuntimeError):
+    pass
+
+
+class EnvCfg(C.Structure):
+    """Mirror of `struct tvc_env_cfg` (include/tvc_native.h)."""
+    _fields_ = [
+        ("mass", C.c_double), ("inertia_xx", C.c_double), ("inertia_zz", C.c_double),
+        ("thrust", C.c_double), ("half_len", C.c_double), ("radius", C.c_double),
+        ("lin_damp", C.c_double), ("ang_damp", C.c_double), ("gravity", C.c_double),
+        ("dt_sub", C.c_double),
+        ("n_sub", C.c_int32), ("max_episode_steps", C.c_int32), ("distinct_window", C.c_int32),
+        ("contact", C.c_int32), ("auto_reset", C.c_int32),
+        ("mu", C.c_double), ("erp", C.c_double), ("cop_s0", C.c_double),
+        ("init_pos", C.c_double * 3), ("init_quat", C.c_double * 4),
+        ("dr_enabled", C.c_int32), ("_pad0", C.c_int32),
+        ("dr_mass_var", C.c_double), ("dr_thrust_std", C.c_double), ("dr_cg_max", C.c_double),
+        ("dr_wind_std", C.c_double), ("dr_init_tilt_max", C.c_double), ("dr_obs_noise_std", C.c_double),
+        ("seed", C.c_uint64), ("env_id_offset", C.c_int64),
+    ]
+
+
+_VP = C.c_void_p
+
+# name -> (restype, argtypes); the export list tests check against include/tvc_native.h
+SIGNATURES = {
+    "tvc_last_error": (C.c_char_p, []),
+    "tvc_abi_version": (C.c_int, []),
+    "tvc_env_default_cfg": (None, [C.POINTER(EnvCfg)]),
+    "tvc_env_create": (C.c_int, [C.POINTER(EnvCfg), C.c_int32, C.c_int32, C.POINTER(_VP)]),
+    "tvc_env_destroy": (None, [_VP]),
+    "tvc_env_num_envs": (C.c_int32, [_VP]),
+    "tvc_env_set_dr": (C.c_int, [_VP, C.POINTER(EnvCfg)]),
+    "tvc_env_reset": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP]),
+    "tvc_env_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "tvc_env_step_many": (C.c_int, [_VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "tvc_env_export_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "tvc_env_import_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "tvc_env_info": (C.c_int, [_VP, _VP, _VP]),
+    "tvc_env_fuel_thresholds": (C.c_int, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+}
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load (building first if needed) libtvc_hip.so and declare the signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build()
+    try:
+        L = C.CDLL(path)
+    except OSError as e:  # fail loudly: the HIP library IS the product
+        raise TvcError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise TvcError(f"{path} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().tvc_last_error()
+        raise TvcError(f"libtvc_hip error {rc}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device=None):
+    return torch.cuda.current_stream(device).cuda_stream

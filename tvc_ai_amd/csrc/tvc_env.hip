@@ -1,0 +1,451 @@
+// libtvc_hip.so -- vector rocket-TVC env: kernels K1 (step) / K2 (reset) and their C ABI.
+//
+// One lane integrates one env; state lives in HBM as struct-of-arrays [field][N] so that every
+// field access of a wavefront is one contiguous 256-byte segment.  The row-major [N,10]
+// observation / [N,2] action tensors the policy side wants are staged through LDS so they leave
+// (enter) the CU as contiguous 16-byte-per-lane stores.
+//
+// Replaces: EnhancedRocketTVCEnv.step/reset, env/enhanced_rocket_tvc_env.py:381-407, 466-518.
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "tvc_common.h"
+#include "tvc_env_device.h"
+
+namespace tvc {
+char* last_error_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+}  // namespace tvc
+
+using namespace tvcdev;
+
+namespace {
+
+constexpr int kMaxBlock = 256;
+
+// ------------------------------------------------------------------ kernels
+
+// Cooperative store of a [rows,10] fp32 tile (LDS, row-major) to global row-major memory.
+__device__ __forceinline__ void store_tile10(const float* tile, float* __restrict__ gbase, int row0, int n_rows_total,
+                                             int rows_in_block) {
+    const int valid_rows = min(rows_in_block, n_rows_total - row0);
+    if (valid_rows <= 0) return;
+    const int n_f = valid_rows * 10;
+    float* g = gbase + (size_t)row0 * 10;
+    const int n_v4 = n_f >> 2;  // row0*10*4 B is 16-B aligned whenever row0 % 2 == 0 (blocks are multiples of 64 rows)
+    const float4* t4 = reinterpret_cast<const float4*>(tile);
+    float4* g4 = reinterpret_cast<float4*>(g);
+    for (int v = threadIdx.x; v < n_v4; v += blockDim.x) g4[v] = t4[v];
+    for (int f = (n_v4 << 2) + threadIdx.x; f < n_f; f += blockDim.x) g[f] = tile[f];
+}
+
+template <bool W10>
+__global__ void __launch_bounds__(kMaxBlock)
+env_step_kernel(EnvBuf b, DevCfg c, const float* __restrict__ act, float* __restrict__ obs, float* __restrict__ rew,
+                unsigned char* __restrict__ term, unsigned char* __restrict__ trunc, float* __restrict__ final_obs,
+                int n_steps) {
+    __shared__ __attribute__((aligned(16))) float tile[kMaxBlock * 10];
+    const int row0 = blockIdx.x * blockDim.x;
+    const int i = row0 + threadIdx.x;
+    const bool valid = i < b.n;
+    const long long gid = c.id_off + i;
+    Regs r;
+    float hw[10];
+    float* ringp = b.ring + (valid ? i : 0);
+    if (valid) {
+        load_regs(r, b, i, c.dr != 0);
+        if (W10) {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) hw[k] = ringp[(size_t)k * b.np];
+        }
+    }
+    for (int t = 0; t < n_steps; ++t) {
+        const size_t toff = (size_t)t * b.n;
+        StepOut o;
+        bool done = false;
+        if (valid) {
+            const float2 a = reinterpret_cast<const float2*>(act)[toff + i];
+            const float a0 = fminf(fmaxf(a.x, -1.0f), 1.0f), a1 = fminf(fmaxf(a.y, -1.0f), 1.0f);  // ref :470
+            physics(r, c, a0, a1);
+            r.step += 1u;  // ref :478
+            epilogue<W10>(r, c, a0, a1, ringp, b.np, hw, o);
+            add_obs_noise(r, c, gid, o.obs);
+            done = (o.term | o.trunc) != 0u;
+            rew[toff + i] = o.reward;
+            term[toff + i] = (unsigned char)o.term;
+            trunc[toff + i] = (unsigned char)o.trunc;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) tile[threadIdx.x * 10 + k] = o.obs[k];
+        }
+        if (final_obs != nullptr) {
+            __syncthreads();
+            store_tile10(tile, final_obs + toff * 10, row0, b.n, blockDim.x);
+            __syncthreads();
+        }
+        if (valid && done && c.auto_reset) {
+            r.episode += 1u;
+            reset_dynamic(r, c, gid);
+            observe(r, c, o.obs);
+            add_obs_noise(r, c, gid, o.obs);
+#pragma unroll
+            for (int k = 0; k < 10; ++k) tile[threadIdx.x * 10 + k] = o.obs[k];
+        }
+        __syncthreads();
+        store_tile10(tile, obs + toff * 10, row0, b.n, blockDim.x);
+        if (t + 1 < n_steps) __syncthreads();
+    }
+    if (valid) store_regs(r, b, i, c.dr != 0);
+}
+
+__global__ void __launch_bounds__(kMaxBlock)
+env_reset_kernel(EnvBuf b, DevCfg c, const unsigned char* __restrict__ mask, int hard, float* __restrict__ obs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n) return;
+    if (mask != nullptr && mask[i] == 0) return;
+    Regs r;
+    load_regs(r, b, i, c.dr != 0);
+    if (hard) {
+        r.run = 0; r.has_pa = 0; r.pa0 = r.pa1 = 0.0f;
+        r.hist_len = 0; r.head = 0; r.distinct = 0;
+        r.episode = 0;
+        for (int k = 0; k < c.W; ++k) b.ring[(size_t)k * b.np + i] = 0.0f;
+    } else {
+        r.episode += 1u;
+    }
+    const long long gid = c.id_off + i;
+    reset_dynamic(r, c, gid);
+    store_regs(r, b, i, true);
+    if (obs != nullptr) {
+        float o[10];
+        observe(r, c, o);
+        add_obs_noise(r, c, gid, o);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) obs[(size_t)i * 10 + k] = o[k];
+    }
+}
+
+// aux layout of the C ABI: step, phase, mission_successful, success_run, hist_len, has_prev_action, distinct, episode
+__global__ void env_export_kernel(EnvBuf b, int W, float* dyn, int* aux, float* pa, float* par, float* hist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n) return;
+    Regs r;
+    load_regs(r, b, i, true);
+    if (dyn) {
+        float* d = dyn + (size_t)i * 13;
+        d[0] = r.px; d[1] = r.py; d[2] = r.pz; d[3] = r.qx; d[4] = r.qy; d[5] = r.qz; d[6] = r.qw;
+        d[7] = r.vx; d[8] = r.vy; d[9] = r.vz; d[10] = r.wx; d[11] = r.wy; d[12] = r.wz;
+    }
+    if (aux) {
+        int* a = aux + (size_t)i * 8;
+        a[0] = r.step; a[1] = r.phase; a[2] = r.msucc; a[3] = r.run; a[4] = r.hist_len; a[5] = r.has_pa;
+        a[6] = r.distinct; a[7] = r.episode;
+    }
+    if (pa) { pa[(size_t)i * 2] = r.pa0; pa[(size_t)i * 2 + 1] = r.pa1; }
+    if (par) {
+        float* p = par + (size_t)i * 8;
+        p[0] = r.ms; p[1] = r.ts; p[2] = r.cg; p[3] = r.windx; p[4] = r.windy; p[5] = r.windz; p[6] = 0.f; p[7] = 0.f;
+    }
+    if (hist) {
+        const unsigned wl = r.hist_len < (unsigned)W ? r.hist_len : (unsigned)W;
+        const unsigned start = wl == (unsigned)W ? r.head : 0u;
+        for (unsigned k = 0; k < (unsigned)W; ++k) {
+            float v = 0.0f;
+            if (k < wl) {
+                unsigned p = start + k;
+                p = p >= (unsigned)W ? p - W : p;
+                v = b.ring[(size_t)p * b.np + i];
+            }
+            hist[(size_t)i * W + k] = v;
+        }
+    }
+}
+
+__global__ void env_import_kernel(EnvBuf b, int W, const float* dyn, const int* aux, const float* pa, const float* par,
+                                  const float* hist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n) return;
+    Regs r;
+    load_regs(r, b, i, true);
+    if (dyn) {
+        const float* d = dyn + (size_t)i * 13;
+        r.px = d[0]; r.py = d[1]; r.pz = d[2]; r.qx = d[3]; r.qy = d[4]; r.qz = d[5]; r.qw = d[6];
+        r.vx = d[7]; r.vy = d[8]; r.vz = d[9]; r.wx = d[10]; r.wy = d[11]; r.wz = d[12];
+    }
+    if (aux) {
+        const int* a = aux + (size_t)i * 8;
+        r.step = a[0]; r.phase = a[1]; r.msucc = a[2]; r.run = a[3]; r.hist_len = a[4]; r.has_pa = a[5];
+        r.distinct = a[6]; r.episode = a[7];
+    }
+    if (pa) { r.pa0 = pa[(size_t)i * 2]; r.pa1 = pa[(size_t)i * 2 + 1]; }
+    if (par) {
+        const float* p = par + (size_t)i * 8;
+        r.ms = p[0]; r.ts = p[1]; r.cg = p[2]; r.windx = p[3]; r.windy = p[4]; r.windz = p[5];
+    }
+    if (hist) {  // oldest first -> physical slots 0.., head = 0
+        for (int k = 0; k < W; ++k) b.ring[(size_t)k * b.np + i] = hist[(size_t)i * W + k];
+        r.head = 0;
+    }
+    store_regs(r, b, i, true);
+}
+
+// info dict of _get_enhanced_info (ref :723-742) as a tensor
+__global__ void env_info_kernel(EnvBuf b, DevCfg c, float* info) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n) return;
+    Regs r;
+    load_regs(r, b, i, false);
+    float x = r.qx, y = r.qy, z = r.qz, w = r.qw;
+    float sarg = -2.0f * (x * z - w * y);
+    float pitch, yaw;
+    if (sarg <= -0.99999f) { pitch = -1.5707963267948966f; yaw = 2.0f * atan2f(x, -y); }
+    else if (sarg >= 0.99999f) { pitch = 1.5707963267948966f; yaw = 2.0f * atan2f(-x, y); }
+    else { pitch = asinf(sarg); yaw = atan2f(2.0f * (x * y + w * z), w * w + x * x - y * y - z * z); }
+    float tilt = sqrtf(pitch * pitch + yaw * yaw);
+    float* o = info + (size_t)i * 8;
+    unsigned k = r.step < (unsigned)c.k_empty ? r.step : (unsigned)c.k_empty;
+    o[0] = r.px; o[1] = r.py; o[2] = r.pz;
+    o[3] = tilt * 57.29577951308232f;
+    o[4] = sqrtf(r.wx * r.wx + r.wy * r.wy + r.wz * r.wz);
+    o[5] = fuel_value(c, k);
+    o[6] = (float)r.phase;
+    o[7] = r.run >= 10u ? 1.0f : 0.0f;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ host side
+
+struct tvc_env {
+    tvc_env_cfg cfg;
+    DevCfg dc;
+    EnvBuf buf;
+    int n;
+    int device;
+    int W;
+    void* slab;
+};
+
+static int fuel_threshold(double thr, bool strict_less) {
+    // first k such that fuel_k < thr (strict_less) or fuel_k <= thr, fuel_k by sequential fp64 subtraction (ref :533)
+    double f = 1.0;
+    for (int k = 0; k <= 100000; ++k) {
+        if (strict_less ? (f < thr) : (f <= thr)) return k;
+        if (!(f > 0.0)) return k;
+        f = f - 0.001;
+        if (f < 0.0) f = 0.0;
+    }
+    return 100000;
+}
+
+static int build_devcfg(const tvc_env_cfg& g, int W, DevCfg& d) {
+    memset(&d, 0, sizeof(d));
+    d.mass = (float)g.mass; d.ixx = (float)g.inertia_xx; d.izz = (float)g.inertia_zz;
+    d.inv_mass = (float)(1.0 / g.mass);
+    d.inv_ixx = (float)(1.0 / g.inertia_xx);
+    d.inv_izz = (float)(1.0 / g.inertia_zz);
+    d.gyro_r = (float)((g.inertia_zz - g.inertia_xx) / g.inertia_xx);
+    d.thrust = (float)g.thrust; d.lever = (float)g.half_len; d.radius = (float)g.radius; d.half_len = (float)g.half_len;
+    d.kl = (float)g.lin_damp; d.ka = (float)g.ang_damp; d.g2 = (float)(2.0 * g.gravity); d.h = (float)g.dt_sub;
+    d.nsub = g.n_sub;
+    d.max_steps = g.max_episode_steps;
+    d.k_empty = fuel_threshold(0.0, false);
+    d.k_coast = fuel_threshold(0.8, true);
+    d.k_low = fuel_threshold(0.1, false);
+    d.contact = g.contact; d.auto_reset = g.auto_reset; d.W = W;
+    d.mu = (float)g.mu; d.erp_over_h = (float)(g.erp / g.dt_sub); d.cop_s0 = (float)g.cop_s0;
+    for (int i = 0; i < 3; ++i) d.init[i] = (float)g.init_pos[i];
+    for (int i = 0; i < 4; ++i) d.init[3 + i] = (float)g.init_quat[i];
+    d.dr = g.dr_enabled;
+    d.dr_mass_var = (float)g.dr_mass_var; d.dr_thrust_std = (float)g.dr_thrust_std; d.dr_cg_max = (float)g.dr_cg_max;
+    d.dr_wind_std = (float)g.dr_wind_std; d.dr_tilt_max = (float)g.dr_init_tilt_max;
+    d.dr_noise_std = (float)g.dr_obs_noise_std;
+    d.seed_lo = (unsigned)(g.seed & 0xFFFFFFFFull); d.seed_hi = (unsigned)(g.seed >> 32);
+    d.id_off = g.env_id_offset;
+    return 0;
+}
+
+static int validate_cfg(const tvc_env_cfg* c) {
+    if (!c) return tvc::set_error(TVC_EINVAL, "cfg is NULL");
+    if (!(c->mass > 0) || !(c->inertia_xx > 0) || !(c->inertia_zz > 0)) return tvc::set_error(TVC_EINVAL, "mass/inertia must be > 0");
+    if (c->n_sub < 1 || c->n_sub > 64) return tvc::set_error(TVC_EINVAL, "n_sub out of range");
+    if (!(c->dt_sub > 0)) return tvc::set_error(TVC_EINVAL, "dt_sub must be > 0");
+    if (c->max_episode_steps < 1 || c->max_episode_steps > 65535) return tvc::set_error(TVC_EINVAL, "max_episode_steps must be in [1, 65535]");
+    if (c->distinct_window != 10 && c->distinct_window != 1000) return tvc::set_error(TVC_EINVAL, "distinct_window must be 10 or 1000");
+    return 0;
+}
+
+extern "C" {
+
+const char* tvc_last_error(void) { return tvc::last_error_buf(); }
+int tvc_abi_version(void) { return TVC_ABI_VERSION; }
+
+void tvc_env_default_cfg(tvc_env_cfg* c) {
+    if (!c) return;
+    memset(c, 0, sizeof(*c));
+    const double mass = 2.0, length = 1.0, radius = 0.05;
+    c->mass = mass;
+    c->inertia_xx = ((1.0 / 12.0) * mass) * (3.0 * (radius * radius) + length * length);
+    c->inertia_zz = ((1.0 / 2.0) * mass) * (radius * radius);
+    c->thrust = 35.0; c->half_len = 0.5; c->radius = radius;
+    c->lin_damp = 0.01; c->ang_damp = 0.02; c->gravity = 9.81;
+    c->dt_sub = 0.02 / 4.0; c->n_sub = 4;
+    c->max_episode_steps = 1000;
+    c->distinct_window = 10;
+    c->contact = 1; c->auto_reset = 1;
+    c->mu = 0.8 * 0.3; c->erp = 0.2; c->cop_s0 = 0.02;
+    c->init_pos[2] = 1.0; c->init_quat[3] = 1.0;
+    c->seed = 42;
+}
+
+int tvc_env_create(const tvc_env_cfg* cfg, int32_t n_envs, int32_t device, tvc_env** out) {
+    if (!out) return tvc::set_error(TVC_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (int e = validate_cfg(cfg)) return e;
+    if (n_envs < 1) return tvc::set_error(TVC_EINVAL, "n_envs must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return tvc::set_error(TVC_ENODEV, "no HIP device visible: libtvc_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return tvc::set_error(TVC_EINVAL, "device %d out of range (%d visible)", device, ndev);
+    TVC_HIP_CHECK(hipSetDevice(device));
+    tvc_env* e = new (std::nothrow) tvc_env();
+    if (!e) return tvc::set_error(TVC_ENOMEM, "host allocation failed");
+    e->cfg = *cfg; e->n = n_envs; e->device = device; e->W = cfg->distinct_window;
+    build_devcfg(*cfg, e->W, e->dc);
+    const int np = tvc::ceil_div(n_envs, 64) * 64;
+    const size_t words = (size_t)np * (13 + 2 + 6 + e->W + 3);
+    hipError_t he = hipMalloc(&e->slab, words * 4);
+    if (he != hipSuccess) {
+        delete e;
+        return tvc::set_error(TVC_ENOMEM, "hipMalloc(%zu bytes) failed: %s", words * 4, hipGetErrorString(he));
+    }
+    float* f = (float*)e->slab;
+    e->buf.dyn = f; f += (size_t)13 * np;
+    e->buf.pa = f; f += (size_t)2 * np;
+    e->buf.par = f; f += (size_t)6 * np;
+    e->buf.ring = f; f += (size_t)e->W * np;
+    e->buf.aux0 = (unsigned*)f; f += np;
+    e->buf.aux1 = (unsigned*)f; f += np;
+    e->buf.epi = (unsigned*)f;
+    e->buf.n = n_envs; e->buf.np = np;
+    he = hipMemset(e->slab, 0, words * 4);
+    if (he != hipSuccess) {
+        (void)hipFree(e->slab);
+        delete e;
+        return tvc::set_error(TVC_EHIP, "hipMemset failed: %s", hipGetErrorString(he));
+    }
+    *out = e;
+    int rc = tvc_env_reset(e, nullptr, 1, nullptr, nullptr);
+    if (rc == 0) {
+        he = hipStreamSynchronize(nullptr);
+        if (he != hipSuccess) rc = tvc::set_error(TVC_EHIP, "reset kernel failed: %s", hipGetErrorString(he));
+    }
+    if (rc != 0) {
+        (void)hipFree(e->slab);
+        delete e;
+        *out = nullptr;
+    }
+    return rc;
+}
+
+void tvc_env_destroy(tvc_env* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipFree(e->slab);
+    delete e;
+}
+
+int32_t tvc_env_num_envs(const tvc_env* e) { return e ? e->n : 0; }
+
+int tvc_env_set_dr(tvc_env* e, const tvc_env_cfg* cfg) {
+    if (!e || !cfg) return tvc::set_error(TVC_EINVAL, "null argument");
+    e->cfg.dr_enabled = cfg->dr_enabled; e->cfg.dr_mass_var = cfg->dr_mass_var; e->cfg.dr_thrust_std = cfg->dr_thrust_std;
+    e->cfg.dr_cg_max = cfg->dr_cg_max; e->cfg.dr_wind_std = cfg->dr_wind_std;
+    e->cfg.dr_init_tilt_max = cfg->dr_init_tilt_max; e->cfg.dr_obs_noise_std = cfg->dr_obs_noise_std;
+    build_devcfg(e->cfg, e->W, e->dc);
+    return 0;
+}
+
+static inline int block_for(int n) { return n >= 65536 ? 256 : 64; }
+
+int tvc_env_reset(tvc_env* e, const uint8_t* mask_dev, int32_t hard, float* obs_dev, void* stream) {
+    if (!e) return tvc::set_error(TVC_EINVAL, "env is NULL");
+    TVC_HIP_CHECK(hipSetDevice(e->device));
+    const int blk = 256;
+    hipLaunchKernelGGL(env_reset_kernel, dim3(tvc::ceil_div(e->n, blk)), dim3(blk), 0, (hipStream_t)stream, e->buf, e->dc,
+                       mask_dev, (int)hard, obs_dev);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int launch_step(tvc_env* e, int n_steps, const float* act, float* obs, float* rew, uint8_t* term, uint8_t* trunc,
+                       float* final_obs, void* stream) {
+    if (!e) return tvc::set_error(TVC_EINVAL, "env is NULL");
+    if (!act || !obs || !rew || !term || !trunc) return tvc::set_error(TVC_EINVAL, "act/obs/rew/term/trunc must be non-NULL");
+    if (n_steps < 1) return tvc::set_error(TVC_EINVAL, "n_steps must be >= 1");
+    if ((reinterpret_cast<uintptr_t>(obs) & 15) || (reinterpret_cast<uintptr_t>(act) & 7) ||
+        (final_obs && (reinterpret_cast<uintptr_t>(final_obs) & 15)))
+        return tvc::set_error(TVC_EINVAL, "obs/final_obs must be 16-byte aligned, act 8-byte aligned");
+    if (n_steps > 1 && (e->n % 2) != 0) return tvc::set_error(TVC_EINVAL, "step_many needs an even number of envs (row alignment)");
+    TVC_HIP_CHECK(hipSetDevice(e->device));
+    const int blk = block_for(e->n);
+    dim3 grid(tvc::ceil_div(e->n, blk)), block(blk);
+    if (e->W == 10)
+        hipLaunchKernelGGL(env_step_kernel<true>, grid, block, 0, (hipStream_t)stream, e->buf, e->dc, act, obs, rew, term,
+                           trunc, final_obs, n_steps);
+    else
+        hipLaunchKernelGGL(env_step_kernel<false>, grid, block, 0, (hipStream_t)stream, e->buf, e->dc, act, obs, rew, term,
+                           trunc, final_obs, n_steps);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int tvc_env_step(tvc_env* e, const float* act_dev, float* obs_dev, float* rew_dev, uint8_t* term_dev, uint8_t* trunc_dev,
+                 float* final_obs_dev, void* stream) {
+    return launch_step(e, 1, act_dev, obs_dev, rew_dev, term_dev, trunc_dev, final_obs_dev, stream);
+}
+
+int tvc_env_step_many(tvc_env* e, int32_t n_steps, const float* act_dev, float* obs_dev, float* rew_dev, uint8_t* term_dev,
+                      uint8_t* trunc_dev, void* stream) {
+    return launch_step(e, n_steps, act_dev, obs_dev, rew_dev, term_dev, trunc_dev, nullptr, stream);
+}
+
+int tvc_env_export_state(tvc_env* e, float* dyn, int32_t* aux, float* pa, float* par, float* hist, void* stream) {
+    if (!e) return tvc::set_error(TVC_EINVAL, "env is NULL");
+    TVC_HIP_CHECK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(env_export_kernel, dim3(tvc::ceil_div(e->n, 256)), dim3(256), 0, (hipStream_t)stream, e->buf, e->W,
+                       dyn, aux, pa, par, hist);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int tvc_env_import_state(tvc_env* e, const float* dyn, const int32_t* aux, const float* pa, const float* par,
+                         const float* hist, void* stream) {
+    if (!e) return tvc::set_error(TVC_EINVAL, "env is NULL");
+    TVC_HIP_CHECK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(env_import_kernel, dim3(tvc::ceil_div(e->n, 256)), dim3(256), 0, (hipStream_t)stream, e->buf, e->W,
+                       dyn, aux, pa, par, hist);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int tvc_env_info(tvc_env* e, float* info_dev, void* stream) {
+    if (!e || !info_dev) return tvc::set_error(TVC_EINVAL, "null argument");
+    TVC_HIP_CHECK(hipSetDevice(e->device));
+    hipLaunchKernelGGL(env_info_kernel, dim3(tvc::ceil_div(e->n, 256)), dim3(256), 0, (hipStream_t)stream, e->buf, e->dc,
+                       info_dev);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int tvc_env_fuel_thresholds(const tvc_env* e, int32_t* k_empty, int32_t* k_coast, int32_t* k_low) {
+    if (!e) return tvc::set_error(TVC_EINVAL, "env is NULL");
+    if (k_empty) *k_empty = e->dc.k_empty;
+    if (k_coast) *k_coast = e->dc.k_coast;
+    if (k_low) *k_low = e->dc.k_low;
+    return 0;
+}
+
+}  // extern "C"
