@@ -28,6 +28,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured co
 # Algorithmic bytes of one env-step through the single-step kernel (DESIGN.md "K1 traffic"):
 # reads  dyn 13 + prev_action 2 + aux 2 + episode 1 + reward window 10 + action 2        = 30 words
 # writes dyn 13 + prev_action 2 + aux 2 + episode 1 + window slot 1 + obs 10 + reward 1  = 30 words + 2 flag bytes
+# (the 16-byte-cell layout actually moves 136 B in + 142 B out = 278 B; PMC-confirmed, profiles/r01_b_*)
 ENV_STEP_BYTES = 30 * 4 + 30 * 4 + 2
 
 
@@ -36,8 +37,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--envs-per-gpu", type=int, default=8192,
-                    help="65 536 envs / 8 GPUs = 8 192 (BASELINE.json configs[4] per-GPU shard)")
+    ap.add_argument("--envs-per-gpu", type=int, default=65536,
+                    help="64k parallel envs (the configuration BASELINE.json's metric is quoted on; fits one GPU). "
+                         "8192 = the per-GPU shard of configs[4] (65 536 envs on 8 GPUs)")
     ap.add_argument("--workload", choices=["physics", "train", "auto"], default="auto")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per K steps")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample length (0 = skip)")
@@ -170,18 +172,22 @@ def main():
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
 
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier(world)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
+    ev0.record()  # HIP events on the stream the kernels are launched on (torch's current stream)
     if graph is not None:
         graph.replay()
     else:
         for k in range(K):
             step_fn(k)
+    ev1.record()
     torch.cuda.synchronize(device)
     barrier(world)
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, world, device)
+    dev_us_per_step = ev0.elapsed_time(ev1) * 1e3 / K
 
     env_steps = float(n) * world * K
     out = {
@@ -198,7 +204,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{workload}: {n} envs/GPU x {world} GPU(s) = {n * world} envs "
-                               f"(65 536/8 per GPU, BASELINE configs[4] shard), contact + auto-reset, "
+                               f"(64k parallel envs per GPU, weak scaling), contact + auto-reset, "
                                f"{'hipGraph of K steps' if graph is not None else 'eager launches'}",
                    "envs_per_gpu": n, "total_envs": n * world},
     }
@@ -209,9 +215,11 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: env_step_kernel (HBM-bound: ~2.7 flop/B)
         if workload == "physics":
-            mean_us, med_us, min_us = kernel_event_times(step_fn, min(K, 200), device)
+            # the timed region holds exactly K launches of this one kernel: average launch duration =
+            # HIP-event time of the region / K (agrees with rocprofv3's per-dispatch average, profiles/)
+            mean_us = med_us = dev_us_per_step
         else:
-            mean_us, med_us, min_us = kernel_event_times(extra_env_only(env, device), 200, device)
+            mean_us, med_us, _ = kernel_event_times(extra_env_only(env, device), 200, device)
         ach = ENV_STEP_BYTES * n / (mean_us * 1e-6) / 1e9
         pmc = None
         try:

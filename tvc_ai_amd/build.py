@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-LIB = os.path.join(CSRC, "libtvc_hip.so")
+LIB = os.environ.get("TVC_HIP_LIB") or os.path.join(CSRC, "libtvc_hip.so")
 SOURCES = ["tvc_env.hip", "tvc_sac.hip", "tvc_replay.hip"]
 ARCH = "gfx950"
 
@@ -27,6 +27,8 @@ def sources():
 
 
 def needs_build():
+    if os.environ.get("TVC_HIP_LIB"):
+        return False  # an explicitly chosen prebuilt variant (kernel A/B experiments)
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
@@ -39,7 +41,8 @@ def build(force=False, verbose=False, extra_flags=()):
     if not force and not needs_build():
         return LIB
     cmd = [_hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
-           "-fno-gpu-rdc", "-ffp-contract=fast", "-Wall", "-Wno-unused-function",
+           "-fno-gpu-rdc", "-ffp-contract=fast", "-fno-slp-vectorize",  # SLP-packed v_pk_* f32 cost 15 % here (A/B in profiles/)
+           "-Wall", "-Wno-unused-function",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC, *extra_flags, "-o", LIB, *sources()]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

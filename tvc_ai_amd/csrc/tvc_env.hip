@@ -42,26 +42,21 @@ __device__ __forceinline__ void store_tile10(const float* tile, float* __restric
     for (int f = (n_v4 << 2) + threadIdx.x; f < n_f; f += blockDim.x) g[f] = tile[f];
 }
 
-template <bool W10>
+template <bool W10, bool DR>
 __global__ void __launch_bounds__(kMaxBlock)
-env_step_kernel(EnvBuf b, DevCfg c, const float* __restrict__ act, float* __restrict__ obs, float* __restrict__ rew,
-                unsigned char* __restrict__ term, unsigned char* __restrict__ trunc, float* __restrict__ final_obs,
-                int n_steps) {
+env_step_kernel(EnvBuf b, DevCfg c, DrCfg d, const float* __restrict__ act, float* __restrict__ obs,
+                float* __restrict__ rew, unsigned char* __restrict__ term, unsigned char* __restrict__ trunc,
+                float* __restrict__ final_obs, int n_steps) {
     __shared__ __attribute__((aligned(16))) float tile[kMaxBlock * 10];
     const int row0 = blockIdx.x * blockDim.x;
     const int i = row0 + threadIdx.x;
     const bool valid = i < b.n;
-    const long long gid = c.id_off + i;
+    const long long gid = DR ? d.id_off + i : 0;
     Regs r;
-    float hw[10];
-    float* ringp = b.ring + (valid ? i : 0);
-    if (valid) {
-        load_regs(r, b, i, c.dr != 0);
-        if (W10) {
-#pragma unroll
-            for (int k = 0; k < 10; ++k) hw[k] = ringp[(size_t)k * b.np];
-        }
-    }
+    float hw[12];
+    float* ringp = W10 ? nullptr : b.ring1000 + (valid ? i : 0);
+    int ring_slot = -1;
+    if (valid) load_regs<DR, W10>(r, hw, b, i);
     for (int t = 0; t < n_steps; ++t) {
         const size_t toff = (size_t)t * b.n;
         StepOut o;
@@ -69,10 +64,10 @@ env_step_kernel(EnvBuf b, DevCfg c, const float* __restrict__ act, float* __rest
         if (valid) {
             const float2 a = reinterpret_cast<const float2*>(act)[toff + i];
             const float a0 = fminf(fmaxf(a.x, -1.0f), 1.0f), a1 = fminf(fmaxf(a.y, -1.0f), 1.0f);  // ref :470
-            physics(r, c, a0, a1);
+            physics<DR>(r, c, a0, a1);
             r.step += 1u;  // ref :478
-            epilogue<W10>(r, c, a0, a1, ringp, b.np, hw, o);
-            add_obs_noise(r, c, gid, o.obs);
+            epilogue<W10>(r, hw, c, a0, a1, ringp, b.np, o, ring_slot);
+            add_obs_noise<DR>(r, d, gid, o.obs);
             done = (o.term | o.trunc) != 0u;
             rew[toff + i] = o.reward;
             term[toff + i] = (unsigned char)o.term;
@@ -87,9 +82,9 @@ env_step_kernel(EnvBuf b, DevCfg c, const float* __restrict__ act, float* __rest
         }
         if (valid && done && c.auto_reset) {
             r.episode += 1u;
-            reset_dynamic(r, c, gid);
+            reset_dynamic<DR>(r, c, d, gid);
             observe(r, c, o.obs);
-            add_obs_noise(r, c, gid, o.obs);
+            add_obs_noise<DR>(r, d, gid, o.obs);
 #pragma unroll
             for (int k = 0; k < 10; ++k) tile[threadIdx.x * 10 + k] = o.obs[k];
         }
@@ -97,31 +92,41 @@ env_step_kernel(EnvBuf b, DevCfg c, const float* __restrict__ act, float* __rest
         store_tile10(tile, obs + toff * 10, row0, b.n, blockDim.x);
         if (t + 1 < n_steps) __syncthreads();
     }
-    if (valid) store_regs(r, b, i, c.dr != 0);
+    if (valid) store_regs<DR, W10>(r, hw, b, i, n_steps == 1 ? ring_slot : 100);
 }
 
 __global__ void __launch_bounds__(kMaxBlock)
-env_reset_kernel(EnvBuf b, DevCfg c, const unsigned char* __restrict__ mask, int hard, float* __restrict__ obs) {
+env_reset_kernel(EnvBuf b, DevCfg c, DrCfg d, int dr, const unsigned char* __restrict__ mask, int hard,
+                 float* __restrict__ obs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b.n) return;
     if (mask != nullptr && mask[i] == 0) return;
     Regs r;
-    load_regs(r, b, i, c.dr != 0);
+    float hw[12];
+    load_regs<true, true>(r, hw, b, i);
     if (hard) {
         r.run = 0; r.has_pa = 0; r.pa0 = r.pa1 = 0.0f;
         r.hist_len = 0; r.head = 0; r.distinct = 0;
         r.episode = 0;
-        for (int k = 0; k < c.W; ++k) b.ring[(size_t)k * b.np + i] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) hw[k] = 0.0f;
+        if (b.ring1000)
+            for (int k = 0; k < 1000; ++k) b.ring1000[(size_t)k * b.np + i] = 0.0f;
     } else {
         r.episode += 1u;
     }
-    const long long gid = c.id_off + i;
-    reset_dynamic(r, c, gid);
-    store_regs(r, b, i, true);
-    if (obs != nullptr) {
-        float o[10];
+    const long long gid = d.id_off + i;
+    float o[10];
+    if (dr) {
+        reset_dynamic<true>(r, c, d, gid);
         observe(r, c, o);
-        add_obs_noise(r, c, gid, o);
+        add_obs_noise<true>(r, d, gid, o);
+    } else {
+        reset_dynamic<false>(r, c, d, gid);
+        observe(r, c, o);
+    }
+    store_regs<true, true>(r, hw, b, i, 100);
+    if (obs != nullptr) {
 #pragma unroll
         for (int k = 0; k < 10; ++k) obs[(size_t)i * 10 + k] = o[k];
     }
@@ -132,7 +137,8 @@ __global__ void env_export_kernel(EnvBuf b, int W, float* dyn, int* aux, float* 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b.n) return;
     Regs r;
-    load_regs(r, b, i, true);
+    float hw[12];
+    load_regs<true, true>(r, hw, b, i);
     if (dyn) {
         float* d = dyn + (size_t)i * 13;
         d[0] = r.px; d[1] = r.py; d[2] = r.pz; d[3] = r.qx; d[4] = r.qy; d[5] = r.qz; d[6] = r.qw;
@@ -151,12 +157,13 @@ __global__ void env_export_kernel(EnvBuf b, int W, float* dyn, int* aux, float* 
     if (hist) {
         const unsigned wl = r.hist_len < (unsigned)W ? r.hist_len : (unsigned)W;
         const unsigned start = wl == (unsigned)W ? r.head : 0u;
+        const float* cellf = reinterpret_cast<const float*>(b.cells);
         for (unsigned k = 0; k < (unsigned)W; ++k) {
             float v = 0.0f;
             if (k < wl) {
                 unsigned p = start + k;
                 p = p >= (unsigned)W ? p - W : p;
-                v = b.ring[(size_t)p * b.np + i];
+                v = (W == 10) ? cellf[((size_t)(6 + (p >> 2)) * b.np + i) * 4 + (p & 3u)] : b.ring1000[(size_t)p * b.np + i];
             }
             hist[(size_t)i * W + k] = v;
         }
@@ -168,7 +175,8 @@ __global__ void env_import_kernel(EnvBuf b, int W, const float* dyn, const int* 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b.n) return;
     Regs r;
-    load_regs(r, b, i, true);
+    float hw[12];
+    load_regs<true, true>(r, hw, b, i);
     if (dyn) {
         const float* d = dyn + (size_t)i * 13;
         r.px = d[0]; r.py = d[1]; r.pz = d[2]; r.qx = d[3]; r.qy = d[4]; r.qz = d[5]; r.qw = d[6];
@@ -185,10 +193,15 @@ __global__ void env_import_kernel(EnvBuf b, int W, const float* dyn, const int* 
         r.ms = p[0]; r.ts = p[1]; r.cg = p[2]; r.windx = p[3]; r.windy = p[4]; r.windz = p[5];
     }
     if (hist) {  // oldest first -> physical slots 0.., head = 0
-        for (int k = 0; k < W; ++k) b.ring[(size_t)k * b.np + i] = hist[(size_t)i * W + k];
+        if (W == 10) {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) hw[k] = hist[(size_t)i * 10 + k];
+        } else {
+            for (int k = 0; k < W; ++k) b.ring1000[(size_t)k * b.np + i] = hist[(size_t)i * W + k];
+        }
         r.head = 0;
     }
-    store_regs(r, b, i, true);
+    store_regs<true, true>(r, hw, b, i, 100);
 }
 
 // info dict of _get_enhanced_info (ref :723-742) as a tensor
@@ -196,7 +209,8 @@ __global__ void env_info_kernel(EnvBuf b, DevCfg c, float* info) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b.n) return;
     Regs r;
-    load_regs(r, b, i, false);
+    float hw[12];
+    load_regs<false, false>(r, hw, b, i);
     float x = r.qx, y = r.qy, z = r.qz, w = r.qw;
     float sarg = -2.0f * (x * z - w * y);
     float pitch, yaw;
@@ -221,6 +235,7 @@ __global__ void env_info_kernel(EnvBuf b, DevCfg c, float* info) {
 struct tvc_env {
     tvc_env_cfg cfg;
     DevCfg dc;
+    DrCfg dr;
     EnvBuf buf;
     int n;
     int device;
@@ -240,30 +255,30 @@ static int fuel_threshold(double thr, bool strict_less) {
     return 100000;
 }
 
-static int build_devcfg(const tvc_env_cfg& g, int W, DevCfg& d) {
+static int build_devcfg(const tvc_env_cfg& g, int W, DevCfg& d, DrCfg& r) {
     memset(&d, 0, sizeof(d));
-    d.mass = (float)g.mass; d.ixx = (float)g.inertia_xx; d.izz = (float)g.inertia_zz;
+    memset(&r, 0, sizeof(r));
     d.inv_mass = (float)(1.0 / g.mass);
     d.inv_ixx = (float)(1.0 / g.inertia_xx);
     d.inv_izz = (float)(1.0 / g.inertia_zz);
     d.gyro_r = (float)((g.inertia_zz - g.inertia_xx) / g.inertia_xx);
     d.thrust = (float)g.thrust; d.lever = (float)g.half_len; d.radius = (float)g.radius; d.half_len = (float)g.half_len;
     d.kl = (float)g.lin_damp; d.ka = (float)g.ang_damp; d.g2 = (float)(2.0 * g.gravity); d.h = (float)g.dt_sub;
+    d.mu = (float)g.mu; d.erp_over_h = (float)(g.erp / g.dt_sub); d.cop_s0 = (float)g.cop_s0;
+    d.inv_max_steps = (float)(1.0 / (double)g.max_episode_steps);
     d.nsub = g.n_sub;
     d.max_steps = g.max_episode_steps;
     d.k_empty = fuel_threshold(0.0, false);
     d.k_coast = fuel_threshold(0.8, true);
     d.k_low = fuel_threshold(0.1, false);
     d.contact = g.contact; d.auto_reset = g.auto_reset; d.W = W;
-    d.mu = (float)g.mu; d.erp_over_h = (float)(g.erp / g.dt_sub); d.cop_s0 = (float)g.cop_s0;
     for (int i = 0; i < 3; ++i) d.init[i] = (float)g.init_pos[i];
     for (int i = 0; i < 4; ++i) d.init[3 + i] = (float)g.init_quat[i];
-    d.dr = g.dr_enabled;
-    d.dr_mass_var = (float)g.dr_mass_var; d.dr_thrust_std = (float)g.dr_thrust_std; d.dr_cg_max = (float)g.dr_cg_max;
-    d.dr_wind_std = (float)g.dr_wind_std; d.dr_tilt_max = (float)g.dr_init_tilt_max;
-    d.dr_noise_std = (float)g.dr_obs_noise_std;
-    d.seed_lo = (unsigned)(g.seed & 0xFFFFFFFFull); d.seed_hi = (unsigned)(g.seed >> 32);
-    d.id_off = g.env_id_offset;
+    r.mass_var = (float)g.dr_mass_var; r.thrust_std = (float)g.dr_thrust_std; r.cg_max = (float)g.dr_cg_max;
+    r.wind_std = (float)g.dr_wind_std; r.tilt_max = (float)g.dr_init_tilt_max;
+    r.noise_std = (float)g.dr_obs_noise_std;
+    r.seed_lo = (unsigned)(g.seed & 0xFFFFFFFFull); r.seed_hi = (unsigned)(g.seed >> 32);
+    r.id_off = g.env_id_offset;
     return 0;
 }
 
@@ -313,24 +328,18 @@ int tvc_env_create(const tvc_env_cfg* cfg, int32_t n_envs, int32_t device, tvc_e
     tvc_env* e = new (std::nothrow) tvc_env();
     if (!e) return tvc::set_error(TVC_ENOMEM, "host allocation failed");
     e->cfg = *cfg; e->n = n_envs; e->device = device; e->W = cfg->distinct_window;
-    build_devcfg(*cfg, e->W, e->dc);
+    build_devcfg(*cfg, e->W, e->dc, e->dr);
     const int np = tvc::ceil_div(n_envs, 64) * 64;
-    const size_t words = (size_t)np * (13 + 2 + 6 + e->W + 3);
-    hipError_t he = hipMalloc(&e->slab, words * 4);
+    const size_t bytes = (size_t)np * kCellGroups * sizeof(float4) + (e->W == 1000 ? (size_t)np * 1000 * sizeof(float) : 0);
+    hipError_t he = hipMalloc(&e->slab, bytes);
     if (he != hipSuccess) {
         delete e;
-        return tvc::set_error(TVC_ENOMEM, "hipMalloc(%zu bytes) failed: %s", words * 4, hipGetErrorString(he));
+        return tvc::set_error(TVC_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(he));
     }
-    float* f = (float*)e->slab;
-    e->buf.dyn = f; f += (size_t)13 * np;
-    e->buf.pa = f; f += (size_t)2 * np;
-    e->buf.par = f; f += (size_t)6 * np;
-    e->buf.ring = f; f += (size_t)e->W * np;
-    e->buf.aux0 = (unsigned*)f; f += np;
-    e->buf.aux1 = (unsigned*)f; f += np;
-    e->buf.epi = (unsigned*)f;
+    e->buf.cells = (float4*)e->slab;
+    e->buf.ring1000 = e->W == 1000 ? (float*)((char*)e->slab + (size_t)np * kCellGroups * sizeof(float4)) : nullptr;
     e->buf.n = n_envs; e->buf.np = np;
-    he = hipMemset(e->slab, 0, words * 4);
+    he = hipMemset(e->slab, 0, bytes);
     if (he != hipSuccess) {
         (void)hipFree(e->slab);
         delete e;
@@ -364,7 +373,7 @@ int tvc_env_set_dr(tvc_env* e, const tvc_env_cfg* cfg) {
     e->cfg.dr_enabled = cfg->dr_enabled; e->cfg.dr_mass_var = cfg->dr_mass_var; e->cfg.dr_thrust_std = cfg->dr_thrust_std;
     e->cfg.dr_cg_max = cfg->dr_cg_max; e->cfg.dr_wind_std = cfg->dr_wind_std;
     e->cfg.dr_init_tilt_max = cfg->dr_init_tilt_max; e->cfg.dr_obs_noise_std = cfg->dr_obs_noise_std;
-    build_devcfg(e->cfg, e->W, e->dc);
+    build_devcfg(e->cfg, e->W, e->dc, e->dr);
     return 0;
 }
 
@@ -375,7 +384,7 @@ int tvc_env_reset(tvc_env* e, const uint8_t* mask_dev, int32_t hard, float* obs_
     TVC_HIP_CHECK(hipSetDevice(e->device));
     const int blk = 256;
     hipLaunchKernelGGL(env_reset_kernel, dim3(tvc::ceil_div(e->n, blk)), dim3(blk), 0, (hipStream_t)stream, e->buf, e->dc,
-                       mask_dev, (int)hard, obs_dev);
+                       e->dr, (int)(e->cfg.dr_enabled != 0), mask_dev, (int)hard, obs_dev);
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -392,12 +401,16 @@ static int launch_step(tvc_env* e, int n_steps, const float* act, float* obs, fl
     TVC_HIP_CHECK(hipSetDevice(e->device));
     const int blk = block_for(e->n);
     dim3 grid(tvc::ceil_div(e->n, blk)), block(blk);
-    if (e->W == 10)
-        hipLaunchKernelGGL(env_step_kernel<true>, grid, block, 0, (hipStream_t)stream, e->buf, e->dc, act, obs, rew, term,
-                           trunc, final_obs, n_steps);
-    else
-        hipLaunchKernelGGL(env_step_kernel<false>, grid, block, 0, (hipStream_t)stream, e->buf, e->dc, act, obs, rew, term,
-                           trunc, final_obs, n_steps);
+    const bool w10 = e->W == 10, dr = e->cfg.dr_enabled != 0;
+    hipStream_t st = (hipStream_t)stream;
+#define TVC_LAUNCH_STEP(A, B)                                                                                         \
+    hipLaunchKernelGGL((env_step_kernel<A, B>), grid, block, 0, st, e->buf, e->dc, e->dr, act, obs, rew, term, trunc, \
+                       final_obs, n_steps)
+    if (w10 && !dr) TVC_LAUNCH_STEP(true, false);
+    else if (w10 && dr) TVC_LAUNCH_STEP(true, true);
+    else if (!w10 && !dr) TVC_LAUNCH_STEP(false, false);
+    else TVC_LAUNCH_STEP(false, true);
+#undef TVC_LAUNCH_STEP
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }

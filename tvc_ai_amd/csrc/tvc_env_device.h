@@ -16,35 +16,39 @@
 namespace tvcdev {
 
 constexpr int kPhaseBoost = 0, kPhaseCoast = 1, kPhaseLanding = 2, kPhaseTouchdown = 3, kPhaseComplete = 5;
+constexpr int kCellGroups = 9;
 
+// hot constants (every env-step); kept small: kernel arguments live in SGPRs
 struct DevCfg {
-    // body / integrator
-    float mass, ixx, izz;
     float inv_mass, inv_ixx, inv_izz, gyro_r;  // gyro_r = (Izz - Ixx) / Ixx
     float thrust, lever, radius, half_len;
     float kl, ka, g2, h;
-    int nsub;
-    // episode bookkeeping
-    int max_steps;
+    float mu, erp_over_h, cop_s0, inv_max_steps;
+    int nsub, max_steps;
     int k_empty, k_coast, k_low;  // fuel is a function of the step count (ref :530-533)
     int contact, auto_reset, W;
-    float mu, erp_over_h, cop_s0;
-    float init[13];
-    // domain randomisation (build-defined)
-    int dr;
-    float dr_mass_var, dr_thrust_std, dr_cg_max, dr_wind_std, dr_tilt_max, dr_noise_std;
+    float init[7];                // pos3, quat4 (velocities start at zero)
+};
+// cold constants: domain randomisation (build-defined), only read by the DR instantiations
+struct DrCfg {
+    float mass_var, thrust_std, cg_max, wind_std, tilt_max, noise_std;
     unsigned seed_lo, seed_hi;
     long long id_off;
 };
 
+// State in HBM: array-of-struct-of-arrays of 16-byte cells, so that every access of a wavefront is one
+// contiguous 1 KiB segment (16 B per lane, the widest coalesced access):
+//   group 0: px py pz  aux0      aux0: step[0:16) phase[16:19) msucc[19] has_pa[20] run[21:28)
+//   group 1: qx qy qz qw
+//   group 2: vx vy vz  aux1      aux1: hist_len[0:10) head[10:20) distinct[20:30)
+//   group 3: wx wy wz  episode
+//   group 4: pa0 pa1 mass_scale thrust_scale
+//   group 5: cg windx windy windz            (read only by DR instantiations)
+//   groups 6,7,8: reward window slots 0-3, 4-7, 8-9 (+2 spare)   (distinct_window == 10)
+// ring1000: [1000][np] floats, only for distinct_window == 1000 (reference-exact mode).
 struct EnvBuf {
-    float* dyn;      // [13][np]
-    float* pa;       // [2][np]  previous clipped action
-    float* par;      // [6][np]  mass_scale, thrust_scale, cg, wind xyz
-    float* ring;     // [W][np]  reward window (physical slots)
-    unsigned* aux0;  // step[0:16) phase[16:19) msucc[19] has_pa[20] run[21:28)
-    unsigned* aux1;  // hist_len[0:10) head[10:20) distinct[20:30)
-    unsigned* epi;   // episode counter (Philox stream)
+    float4* cells;    // [kCellGroups][np]
+    float* ring1000;  // [1000][np] or nullptr
     int n, np;
 };
 
@@ -62,6 +66,8 @@ struct StepOut {
     float reward;
     unsigned term, trunc;
 };
+
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // ------------------------------------------------------------------ Philox4x32-10 (Random123)
 __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
@@ -102,7 +108,7 @@ struct Mat3 {
 // btMatrix3x3::setRotation (pybullet.getMatrixFromQuaternion, ref :546)
 __device__ __forceinline__ Mat3 rotmat(float x, float y, float z, float w) {
     float d = x * x + y * y + z * z + w * w;
-    float s = 2.0f * __builtin_amdgcn_rcpf(d);
+    float s = 2.0f * rcp(d);
     float xs = x * s, ys = y * s, zs = z * s;
     float wx = w * xs, wy = w * ys, wz = w * zs;
     float xx = x * xs, xy = x * ys, xz = x * zs;
@@ -116,9 +122,8 @@ __device__ __forceinline__ Mat3 rotmat(float x, float y, float z, float w) {
 __device__ __forceinline__ float clamp100(float v) { return fminf(fmaxf(v, -100.0f), 100.0f); }
 
 // Build-defined ground contact, same model as oracle/tvc_oracle.c ground_contact().
-__device__ __forceinline__ void contact_impulse(Regs& r, const DevCfg& c, const Mat3& R, float rx, float ry, float rz,
-                                                float dx, float dy, float dz, float j, float inv_m, float inv_ixx,
-                                                float inv_izz) {
+__device__ __forceinline__ void contact_impulse(Regs& r, const Mat3& R, float rx, float ry, float rz, float dx, float dy,
+                                                float dz, float j, float inv_m, float inv_ixx, float inv_izz) {
     r.vx += j * dx * inv_m; r.vy += j * dy * inv_m; r.vz += j * dz * inv_m;
     float cx = ry * dz - rz * dy, cy = rz * dx - rx * dz, cz = rx * dy - ry * dx;
     float lx = (R.m00 * cx + R.m10 * cy + R.m20 * cz) * inv_ixx;
@@ -140,12 +145,12 @@ __device__ __forceinline__ float contact_kinv(const Mat3& R, float rx, float ry,
     float ex = wy * rz - wz * ry, ey = wz * rx - wx * rz, ez = wx * ry - wy * rx;
     return inv_m + dx * ex + dy * ey + dz * ez;
 }
-__device__ __forceinline__ void ground_contact(Regs& r, const DevCfg& c, float inv_m, float inv_ixx, float inv_izz) {
-    Mat3 R = rotmat(r.qx, r.qy, r.qz, r.qw);
+__device__ __forceinline__ void ground_contact(Regs& r, const DevCfg& c, const Mat3& R, float inv_m, float inv_ixx,
+                                               float inv_izz) {
     float ax = R.m02, ay = R.m12, az = R.m22;
     float dx = az * ax, dy = az * ay, dz = az * az - 1.0f;
     float dn = __builtin_sqrtf(dx * dx + dy * dy + dz * dz);
-    float sc = dn > c.cop_s0 ? c.radius / dn : c.radius / c.cop_s0;
+    float sc = c.radius * rcp(fmaxf(dn, c.cop_s0));
 #pragma unroll
     for (int end = 0; end < 2; ++end) {
         float L = end == 0 ? -(c.half_len + r.cg) : (c.half_len - r.cg);
@@ -155,44 +160,46 @@ __device__ __forceinline__ void ground_contact(Regs& r, const DevCfg& c, float i
         float depth = -pz;
         float vn = r.vz + (r.wx * ry - r.wy * rx);
         float kn = contact_kinv(R, rx, ry, rz, 0.0f, 0.0f, 1.0f, inv_m, inv_ixx, inv_izz);
-        float jn = (-vn + c.erp_over_h * depth) / kn;
+        float jn = (-vn + c.erp_over_h * depth) * rcp(kn);
         if (jn <= 0.0f) continue;
-        contact_impulse(r, c, R, rx, ry, rz, 0.0f, 0.0f, 1.0f, jn, inv_m, inv_ixx, inv_izz);
+        contact_impulse(r, R, rx, ry, rz, 0.0f, 0.0f, 1.0f, jn, inv_m, inv_ixx, inv_izz);
         float tx = r.vx + (r.wy * rz - r.wz * ry);
         float ty = r.vy + (r.wz * rx - r.wx * rz);
         float vtn = __builtin_sqrtf(tx * tx + ty * ty);
         if (vtn > 1e-9f) {
-            tx /= vtn; ty /= vtn;
+            float iv = rcp(vtn);
+            tx *= iv; ty *= iv;
             float kt = contact_kinv(R, rx, ry, rz, tx, ty, 0.0f, inv_m, inv_ixx, inv_izz);
-            float jt = fminf(vtn / kt, c.mu * jn);
-            contact_impulse(r, c, R, rx, ry, rz, tx, ty, 0.0f, -jt, inv_m, inv_ixx, inv_izz);
+            float jt = fminf(vtn * rcp(kt), c.mu * jn);
+            contact_impulse(r, R, rx, ry, rz, tx, ty, 0.0f, -jt, inv_m, inv_ixx, inv_izz);
         }
     }
 }
 
 // ------------------------------------------------------------------ reset (ref :381-407 + build-defined DR)
-__device__ __forceinline__ void reset_dynamic(Regs& r, const DevCfg& c, long long gid) {
+template <bool DR>
+__device__ __forceinline__ void reset_dynamic(Regs& r, const DevCfg& c, const DrCfg& d, long long gid) {
     r.px = c.init[0]; r.py = c.init[1]; r.pz = c.init[2];
     r.qx = c.init[3]; r.qy = c.init[4]; r.qz = c.init[5]; r.qw = c.init[6];
     r.vx = r.vy = r.vz = 0.0f;
     r.wx = r.wy = r.wz = 0.0f;
     r.step = 0; r.phase = kPhaseBoost; r.msucc = 0;
     r.ms = 1.0f; r.ts = 1.0f; r.cg = 0.0f; r.windx = r.windy = r.windz = 0.0f;
-    if (c.dr) {
+    if (DR) {
         unsigned u[4], v[4];
         unsigned long long g = (unsigned long long)gid;
-        philox4x32_10((unsigned)g, (unsigned)(g >> 32), r.episode, 0u, c.seed_lo, c.seed_hi, u);
-        philox4x32_10((unsigned)g, (unsigned)(g >> 32), r.episode, 1u, c.seed_lo, c.seed_hi, v);
-        r.ms = 1.0f + c.dr_mass_var * usym(u[0]);
-        r.cg = c.dr_cg_max * usym(u[1]);
-        float tx = c.dr_tilt_max * usym(u[2]), ty = c.dr_tilt_max * usym(u[3]);
+        philox4x32_10((unsigned)g, (unsigned)(g >> 32), r.episode, 0u, d.seed_lo, d.seed_hi, u);
+        philox4x32_10((unsigned)g, (unsigned)(g >> 32), r.episode, 1u, d.seed_lo, d.seed_hi, v);
+        r.ms = 1.0f + d.mass_var * usym(u[0]);
+        r.cg = d.cg_max * usym(u[1]);
+        float tx = d.tilt_max * usym(u[2]), ty = d.tilt_max * usym(u[3]);
         float z0, z1, z2, z3;
         box_muller(v[0], v[1], z0, z1);
         box_muller(v[2], v[3], z2, z3);
-        r.ts = fminf(fmaxf(1.0f + c.dr_thrust_std * z0, 0.5f), 1.5f);
-        r.windx = c.dr_wind_std * z1;
-        r.windy = c.dr_wind_std * z2;
-        if (c.dr_tilt_max > 0.0f) {
+        r.ts = fminf(fmaxf(1.0f + d.thrust_std * z0, 0.5f), 1.5f);
+        r.windx = d.wind_std * z1;
+        r.windy = d.wind_std * z2;
+        if (d.tilt_max > 0.0f) {
             float sx = __sinf(0.5f * tx), cx = __cosf(0.5f * tx), sy = __sinf(0.5f * ty), cy = __cosf(0.5f * ty);
             // qt = qy(ty) (x) qx(tx); q = qt (x) init
             float x1 = cy * sx, y1 = sy * cx, z1q = -sy * sx, w1 = cy * cx;
@@ -212,54 +219,65 @@ __device__ __forceinline__ float fuel_value(const DevCfg& c, unsigned k) {
     return k >= (unsigned)c.k_empty ? 0.0f : (float)__builtin_fma(-0.001, (double)k, 1.0);
 }
 
+__device__ __forceinline__ float phase_value(unsigned p) {
+    // float32(phase_idx / 7.0), ref :593 (list(MissionPhase).index / len(MissionPhase))
+    return p == 0u ? 0.0f : p == 1u ? 0.14285715f : p == 2u ? 0.2857143f : p == 3u ? 0.42857143f
+         : p == 4u ? 0.5714286f : p == 5u ? 0.71428573f : 0.85714287f;
+}
+
 __device__ __forceinline__ void observe(const Regs& r, const DevCfg& c, float o[10]) {
     unsigned k = r.step < (unsigned)c.k_empty ? r.step : (unsigned)c.k_empty;
     o[0] = r.qx; o[1] = r.qy; o[2] = r.qz; o[3] = r.qw;
     o[4] = r.wx; o[5] = r.wy; o[6] = r.wz;
     o[7] = fuel_value(c, k);
-    // float32(phase_idx / 7.0), ref :593 (list(MissionPhase).index / len(MissionPhase))
-    const float ph = (float)r.phase;
-    o[8] = r.phase == 0u ? 0.0f : r.phase == 1u ? 0.14285715f : r.phase == 2u ? 0.2857143f : r.phase == 3u ? 0.42857143f
-         : r.phase == 4u ? 0.5714286f : r.phase == 5u ? 0.71428573f : 0.85714287f;
-    (void)ph;
-    o[9] = fminf(1.0f, (float)r.step / (float)c.max_steps);
+    o[8] = phase_value(r.phase);
+    o[9] = fminf(1.0f, (float)r.step * c.inv_max_steps);
 }
 
-__device__ __forceinline__ void add_obs_noise(const Regs& r, const DevCfg& c, long long gid, float o[10]) {
-    if (c.dr && c.dr_noise_std > 0.0f) {
-        unsigned u[4], v[4];
-        unsigned long long g = (unsigned long long)gid;
-        philox4x32_10((unsigned)g, (unsigned)(g >> 32), r.episode, 0x10000u + r.step * 2u, c.seed_lo, c.seed_hi, u);
-        philox4x32_10((unsigned)g, (unsigned)(g >> 32), r.episode, 0x10001u + r.step * 2u, c.seed_lo, c.seed_hi, v);
-        float z[8];
-        box_muller(u[0], u[1], z[0], z[1]);
-        box_muller(u[2], u[3], z[2], z[3]);
-        box_muller(v[0], v[1], z[4], z[5]);
-        box_muller(v[2], v[3], z[6], z[7]);
+template <bool DR>
+__device__ __forceinline__ void add_obs_noise(const Regs& r, const DrCfg& d, long long gid, float o[10]) {
+    if (DR) {
+        if (d.noise_std > 0.0f) {
+            unsigned u[4], v[4];
+            unsigned long long g = (unsigned long long)gid;
+            philox4x32_10((unsigned)g, (unsigned)(g >> 32), r.episode, 0x10000u + r.step * 2u, d.seed_lo, d.seed_hi, u);
+            philox4x32_10((unsigned)g, (unsigned)(g >> 32), r.episode, 0x10001u + r.step * 2u, d.seed_lo, d.seed_hi, v);
+            float z[8];
+            box_muller(u[0], u[1], z[0], z[1]);
+            box_muller(u[2], u[3], z[2], z[3]);
+            box_muller(v[0], v[1], z[4], z[5]);
+            box_muller(v[2], v[3], z[6], z[7]);
 #pragma unroll
-        for (int i = 0; i < 7; ++i) o[i] += c.dr_noise_std * z[i];
+            for (int i = 0; i < 7; ++i) o[i] += d.noise_std * z[i];
+        }
     }
 }
 
 // ------------------------------------------------------------------ physics half
+template <bool DR>
 __device__ __forceinline__ void physics(Regs& r, const DevCfg& c, float a0, float a1) {
-    const float inv_m = c.inv_mass / r.ms, inv_ixx = c.inv_ixx / r.ms, inv_izz = c.inv_izz / r.ms;
+    float inv_m = c.inv_mass, inv_ixx = c.inv_ixx, inv_izz = c.inv_izz;
+    if (DR) {
+        float ims = rcp(r.ms);
+        inv_m *= ims; inv_ixx *= ims; inv_izz *= ims;
+    }
     Mat3 R = rotmat(r.qx, r.qy, r.qz, r.qw);
-    // linear acceleration (world) and torque (world), held for the whole control step
-    float fx = r.windx, fy = r.windy, fz = r.windz;  // forces other than gravity
+    // force other than gravity (world) and torque (world), held for the whole control step
+    float fx = 0.0f, fy = 0.0f, fz = 0.0f;
+    if (DR) { fx = r.windx; fy = r.windy; fz = r.windz; }
     float tqx = 0.0f, tqy = 0.0f, tqz = 0.0f;
     if (r.step < (unsigned)c.k_empty) {  // fuel > 0 before the decrement (ref :530)
         float pitch = a0 * 0.3141592653589793f, yaw = a1 * 0.3141592653589793f;
         float p2 = pitch * pitch, y2 = yaw * yaw;
         float sp = pitch * sinc_small(p2), cp = cos_small(p2);
         float sy = yaw * sinc_small(y2), cy = cos_small(y2);
-        float T = c.thrust * r.ts;
+        float T = DR ? c.thrust * r.ts : c.thrust;
         float tlx = T * sy, tly = T * sp, tlz = T * cp * cy;  // ref :539-543
         fx += R.m00 * tlx + R.m01 * tly + R.m02 * tlz;
         fy += R.m10 * tlx + R.m11 * tly + R.m12 * tlz;
         fz += R.m20 * tlx + R.m21 * tly + R.m22 * tlz;
         // (0,0,-L) x Tl in the body frame = (L*Tly, -L*Tlx, 0)   (ref :550-556)
-        float L = c.lever + r.cg;
+        float L = DR ? c.lever + r.cg : c.lever;
         float bx = L * tly, by = -L * tlx;
         tqx += R.m00 * bx + R.m01 * by;
         tqy += R.m10 * bx + R.m11 * by;
@@ -302,15 +320,14 @@ __device__ __forceinline__ void physics(Regs& r, const DevCfg& c, float a0, floa
         r.vy = clamp100(r.vy + h * (acy - r.vy * dl));
         r.vz = clamp100(r.vz + h * (acz - r.vz * dl));
         if (c.contact) {
-            float reach = fabsf(R.m22) * (c.half_len + fabsf(r.cg)) + c.radius;
-            if (r.pz - reach <= 0.0f) ground_contact(r, c, inv_m, inv_ixx, inv_izz);
+            float reach = fabsf(R.m22) * (c.half_len + (DR ? fabsf(r.cg) : 0.0f)) + c.radius;
+            if (r.pz - reach <= 0.0f) ground_contact(r, c, R, inv_m, inv_ixx, inv_izz);
         }
         r.px += h * r.vx; r.py += h * r.vy; r.pz += h * r.vz;
         // exponential map, q' = normalize(dq (x) q)
         float wn2 = r.wx * r.wx + r.wy * r.wy + r.wz * r.wz;
         float wn = __builtin_sqrtf(wn2);
-        float fa = wn;
-        if (wn * h > 0.7853981633974483f) fa = 0.7853981633974483f / h;
+        float fa = fminf(wn, 0.7853981633974483f * rcp(h));  // Bullet: clamp |w| h to pi/4
         float xh = 0.5f * fa * h, xh2 = xh * xh;
         float k = 0.5f * h * sinc_small(xh2);  // sin(xh)/fa
         float x1 = r.wx * k, y1 = r.wy * k, z1 = r.wz * k, w1 = cos_small(xh2);
@@ -319,19 +336,18 @@ __device__ __forceinline__ void physics(Regs& r, const DevCfg& c, float a0, floa
         float ny = w1 * y2 + y1 * w2 + z1 * x2 - x1 * z2;
         float nz = w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2;
         float nq = w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2;
-        float il = __builtin_amdgcn_rsqf(nx * nx + ny * ny + nz * nz + nq * nq);
-        // one Newton step on rsq keeps |q| = 1 to fp32 rounding
         float l2 = nx * nx + ny * ny + nz * nz + nq * nq;
-        il = il * (1.5f - 0.5f * l2 * il * il);
+        float il = __builtin_amdgcn_rsqf(l2);
+        il = il * (1.5f - 0.5f * l2 * il * il);  // one Newton step: |q| = 1 to fp32 rounding
         r.qx = nx * il; r.qy = ny * il; r.qz = nz * il; r.qw = nq * il;
     }
 }
 
 // ------------------------------------------------------------------ logic half + reward
-// hw: the reward window's physical slots for W == 10 (registers); ringp: this env's column for W != 10.
+// W10: the reward window lives in hw (registers, static indexing only); else in ringp (this env's column of ring1000).
 template <bool W10>
-__device__ __forceinline__ void epilogue(Regs& r, const DevCfg& c, float a0, float a1, float* __restrict__ ringp,
-                                         int np, float hw[10], StepOut& out) {
+__device__ __forceinline__ void epilogue(Regs& r, float (&hw)[12], const DevCfg& c, float a0, float a1,
+                                         float* __restrict__ ringp, int np, StepOut& out, int& ring_slot) {
     // derived scalars (ref :608-633)
     float x = r.qx, y = r.qy, z = r.qz, w = r.qw;
     float sarg = -2.0f * (x * z - w * y);
@@ -383,7 +399,7 @@ __device__ __forceinline__ void epilogue(Regs& r, const DevCfg& c, float a0, flo
     float tilt_pen = __expf(-10.0f * fmaxf(0.0f, tilt - 0.087f));
     float ang_pen = __expf(-5.0f * fmaxf(0.0f, wmag - 0.1f));
     float alt_pen = (0.2f <= alt && alt <= 20.0f) ? 1.0f : 0.5f;
-    float safe = (tilt_pen + ang_pen + alt_pen) / 3.0f;
+    float safe = (tilt_pen + ang_pen + alt_pen) * (1.0f / 3.0f);
     float ce = __builtin_sqrtf(a0 * a0 + a1 * a1);
     float fe = (k < (unsigned)c.k_low && ce < 0.5f) ? fuel * (1.0f - ce) : 0.0f;
     float stab = (tilt < 0.05f && wmag < 0.1f) ? 1.0f : ((tilt < 0.1f && wmag < 0.2f) ? 0.5f : 0.0f);
@@ -444,9 +460,8 @@ __device__ __forceinline__ void epilogue(Regs& r, const DevCfg& c, float a0, flo
     // append to the window, maintain the distinct count incrementally
     {
         bool e_dup = false, v_dup = false;
-        float ev;
         if (W10) {
-            ev = 0.0f;
+            float ev = 0.0f;
 #pragma unroll
             for (int i = 0; i < 10; ++i) ev = ((unsigned)i == slot) ? hw[i] : ev;
 #pragma unroll
@@ -458,15 +473,16 @@ __device__ __forceinline__ void epilogue(Regs& r, const DevCfg& c, float a0, flo
 #pragma unroll
             for (int i = 0; i < 10; ++i) hw[i] = ((unsigned)i == slot) ? total : hw[i];
         } else {
-            ev = full ? ringp[(size_t)slot * np] : 0.0f;
+            float ev = full ? ringp[(size_t)slot * np] : 0.0f;
             for (unsigned i = 0; i < wl; ++i) {
                 if (i == slot) continue;
                 float hv = ringp[(size_t)i * np];
                 e_dup |= (hv == ev);
                 v_dup |= (hv == total);
             }
+            ringp[(size_t)slot * np] = total;
         }
-        ringp[(size_t)slot * np] = total;
+        ring_slot = (int)slot;
         unsigned d = r.distinct;
         if (full && !e_dup) d -= 1u;
         if (!v_dup) d += 1u;
@@ -481,7 +497,7 @@ __device__ __forceinline__ void epilogue(Regs& r, const DevCfg& c, float a0, flo
     if (r.msucc) {
         term = 1;
     } else {
-        if (crashed || tilt > 0.52f || alt > 20.0f || __builtin_sqrtf(r.px * r.px + r.py * r.py) > 50.0f) term = 1;
+        if (crashed || tilt > 0.52f || alt > 20.0f || (r.px * r.px + r.py * r.py) > 2500.0f) term = 1;
         if (r.step >= (unsigned)c.max_steps) trunc = 1;
     }
     out.term = term;
@@ -489,40 +505,60 @@ __device__ __forceinline__ void epilogue(Regs& r, const DevCfg& c, float a0, flo
 }
 
 // ------------------------------------------------------------------ state <-> registers
-__device__ __forceinline__ void load_regs(Regs& r, const EnvBuf& b, int i, bool dr) {
-    const float* d = b.dyn + i;
+template <bool DR, bool W10>
+__device__ __forceinline__ void load_regs(Regs& r, float (&hw)[12], const EnvBuf& b, int i) {
+    const float4* c = b.cells + i;
     const size_t np = b.np;
-    r.px = d[0 * np]; r.py = d[1 * np]; r.pz = d[2 * np];
-    r.qx = d[3 * np]; r.qy = d[4 * np]; r.qz = d[5 * np]; r.qw = d[6 * np];
-    r.vx = d[7 * np]; r.vy = d[8 * np]; r.vz = d[9 * np];
-    r.wx = d[10 * np]; r.wy = d[11 * np]; r.wz = d[12 * np];
-    r.pa0 = b.pa[i]; r.pa1 = b.pa[np + i];
-    unsigned a0 = b.aux0[i], a1 = b.aux1[i];
+    float4 g0 = c[0], g1 = c[np], g2 = c[2 * np], g3 = c[3 * np], g4 = c[4 * np];
+    r.px = g0.x; r.py = g0.y; r.pz = g0.z;
+    r.qx = g1.x; r.qy = g1.y; r.qz = g1.z; r.qw = g1.w;
+    r.vx = g2.x; r.vy = g2.y; r.vz = g2.z;
+    r.wx = g3.x; r.wy = g3.y; r.wz = g3.z;
+    r.pa0 = g4.x; r.pa1 = g4.y; r.ms = g4.z; r.ts = g4.w;
+    unsigned a0 = __float_as_uint(g0.w), a1 = __float_as_uint(g2.w);
     r.step = a0 & 0xFFFFu; r.phase = (a0 >> 16) & 7u; r.msucc = (a0 >> 19) & 1u; r.has_pa = (a0 >> 20) & 1u;
     r.run = (a0 >> 21) & 127u;
     r.hist_len = a1 & 1023u; r.head = (a1 >> 10) & 1023u; r.distinct = (a1 >> 20) & 1023u;
-    r.episode = b.epi[i];
-    if (dr) {
-        const float* p = b.par + i;
-        r.ms = p[0]; r.ts = p[np]; r.cg = p[2 * np]; r.windx = p[3 * np]; r.windy = p[4 * np]; r.windz = p[5 * np];
+    r.episode = __float_as_uint(g3.w);
+    if (DR) {
+        float4 g5 = c[5 * np];
+        r.cg = g5.x; r.windx = g5.y; r.windy = g5.z; r.windz = g5.w;
     } else {
-        r.ms = 1.0f; r.ts = 1.0f; r.cg = 0.0f; r.windx = r.windy = r.windz = 0.0f;
+        r.cg = 0.0f; r.windx = r.windy = r.windz = 0.0f;
+    }
+    if (W10) {
+        float4 h0 = c[6 * np], h1 = c[7 * np], h2 = c[8 * np];
+        hw[0] = h0.x; hw[1] = h0.y; hw[2] = h0.z; hw[3] = h0.w;
+        hw[4] = h1.x; hw[5] = h1.y; hw[6] = h1.z; hw[7] = h1.w;
+        hw[8] = h2.x; hw[9] = h2.y; hw[10] = h2.z; hw[11] = h2.w;
     }
 }
-__device__ __forceinline__ void store_regs(const Regs& r, const EnvBuf& b, int i, bool dr_params) {
-    float* d = b.dyn + i;
+// ring_slot: the window slot written this step (W10; -1 = none, 100 = all three groups)
+template <bool DR, bool W10>
+__device__ __forceinline__ void store_regs(const Regs& r, const float (&hw)[12], const EnvBuf& b, int i, int ring_slot) {
+    float4* c = b.cells + i;
     const size_t np = b.np;
-    d[0 * np] = r.px; d[1 * np] = r.py; d[2 * np] = r.pz;
-    d[3 * np] = r.qx; d[4 * np] = r.qy; d[5 * np] = r.qz; d[6 * np] = r.qw;
-    d[7 * np] = r.vx; d[8 * np] = r.vy; d[9 * np] = r.vz;
-    d[10 * np] = r.wx; d[11 * np] = r.wy; d[12 * np] = r.wz;
-    b.pa[i] = r.pa0; b.pa[np + i] = r.pa1;
-    b.aux0[i] = (r.step & 0xFFFFu) | (r.phase << 16) | (r.msucc << 19) | (r.has_pa << 20) | (r.run << 21);
-    b.aux1[i] = r.hist_len | (r.head << 10) | (r.distinct << 20);
-    b.epi[i] = r.episode;
-    if (dr_params) {
-        float* p = b.par + i;
-        p[0] = r.ms; p[np] = r.ts; p[2 * np] = r.cg; p[3 * np] = r.windx; p[4 * np] = r.windy; p[5 * np] = r.windz;
+    unsigned a0 = (r.step & 0xFFFFu) | (r.phase << 16) | (r.msucc << 19) | (r.has_pa << 20) | (r.run << 21);
+    unsigned a1 = r.hist_len | (r.head << 10) | (r.distinct << 20);
+    c[0] = make_float4(r.px, r.py, r.pz, __uint_as_float(a0));
+    c[np] = make_float4(r.qx, r.qy, r.qz, r.qw);
+    c[2 * np] = make_float4(r.vx, r.vy, r.vz, __uint_as_float(a1));
+    c[3 * np] = make_float4(r.wx, r.wy, r.wz, __uint_as_float(r.episode));
+    c[4 * np] = make_float4(r.pa0, r.pa1, r.ms, r.ts);
+    if (DR) c[5 * np] = make_float4(r.cg, r.windx, r.windy, r.windz);
+    if (W10) {
+        if (ring_slot == 100) {
+            c[6 * np] = make_float4(hw[0], hw[1], hw[2], hw[3]);
+            c[7 * np] = make_float4(hw[4], hw[5], hw[6], hw[7]);
+            c[8 * np] = make_float4(hw[8], hw[9], hw[10], hw[11]);
+        } else if (ring_slot >= 0) {
+            // only the 16-byte cell that holds the slot appended this step goes back to HBM
+            const int g = ring_slot >> 2;
+            float4 v = g == 0 ? make_float4(hw[0], hw[1], hw[2], hw[3])
+                     : g == 1 ? make_float4(hw[4], hw[5], hw[6], hw[7])
+                              : make_float4(hw[8], hw[9], hw[10], hw[11]);
+            c[(size_t)(6 + g) * np] = v;
+        }
     }
 }
 
