@@ -1,0 +1,158 @@
+"""Eager-PyTorch fp32 restatement of the reference SAC learner (test infrastructure only).
+
+It is the checker for the HIP learner kernels: pinned against golden vectors taken from the reference's
+own code (tests/golden/sac_ref.npz, tests/test_sac_oracle_golden.py), then used on the GPU box -- where
+/root/reference does not exist -- as the fp32 reference the kernels are compared with.
+
+Follows, with parameters addressed by the reference's state_dict names:
+  TransformerPolicyNetwork.forward   agent/multi_algorithm_agent.py:192-227 (seq-len 1: attention == out_proj(v_proj(x)),
+                                     SURVEY F8; positional encoding row-indexed by BATCH position)
+  critics                            :593-615
+  _update_sac                        :950-1016   (gamma .99, alpha .2, tau .005, three Adam(lr 3e-4))
+  PhysicsInformedLoss.forward        :236-285
+Never imported by the product package.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+GAMMA, ALPHA, TAU, LR = 0.99, 0.2, 0.005, 3e-4
+
+
+def positional_encoding(n_rows, d_model=256):
+    """PositionalEncoding buffer rows 0..n_rows-1 (agent/...:93-102)."""
+    pe = torch.zeros(n_rows, d_model)
+    position = torch.arange(0, n_rows, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-np.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+def _ln(x, P, name, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), P[name + ".weight"], P[name + ".bias"], eps)
+
+
+def actor_forward(P, obs, batch_pe=False, n_layers=4):
+    """-> mean[B,A], log_std[B,A] (clamped to [-20, 2]).  batch_pe=True reproduces the reference's
+    row-indexed positional encoding (row b gets PE(b)); False = PE(0) on every row (== reference at B=1)."""
+    d = P["input_embedding.weight"].shape[0]
+    x = obs @ P["input_embedding.weight"].T + P["input_embedding.bias"]
+    pe = positional_encoding(obs.shape[0] if batch_pe else 1, d).to(obs)
+    x = x + pe
+    for l in range(n_layers):
+        pre = f"transformer_encoder.layers.{l}."
+        Wv = P[pre + "self_attn.in_proj_weight"][2 * d:3 * d]
+        bv = P[pre + "self_attn.in_proj_bias"][2 * d:3 * d]
+        v = x @ Wv.T + bv
+        a = v @ P[pre + "self_attn.out_proj.weight"].T + P[pre + "self_attn.out_proj.bias"]
+        x = _ln(x + a, P, pre + "norm1")
+        f = F.gelu(x @ P[pre + "linear1.weight"].T + P[pre + "linear1.bias"])
+        f = f @ P[pre + "linear2.weight"].T + P[pre + "linear2.bias"]
+        x = _ln(x + f, P, pre + "norm2")
+    x = _ln(x, P, "feature_norm")
+    h = _ln(F.gelu(x @ P["policy_head.0.weight"].T + P["policy_head.0.bias"]), P, "policy_head.2")
+    h = _ln(F.gelu(h @ P["policy_head.4.weight"].T + P["policy_head.4.bias"]), P, "policy_head.6")
+    out = h @ P["policy_head.8.weight"].T + P["policy_head.8.bias"]
+    a_dim = out.shape[1] // 2
+    return out[:, :a_dim], torch.clamp(out[:, a_dim:], -20, 2)
+
+
+def critic_forward(Q, s, a):
+    x = torch.cat([s, a], -1)
+    h = _ln(F.gelu(x @ Q["0.weight"].T + Q["0.bias"]), Q, "2")
+    h = _ln(F.gelu(h @ Q["4.weight"].T + Q["4.bias"]), Q, "6")
+    return (h @ Q["8.weight"].T + Q["8.bias"]).squeeze(-1)
+
+
+def physics_loss(states, actions, next_states, weight=0.1):
+    """agent/...:236-285; returns (total, [momentum, energy, quat_norm])."""
+    w, w2 = states[:, 4:7], next_states[:, 4:7]
+    ctrl = actions.norm(dim=1, keepdim=True).repeat(1, 3) * 0.1
+    mom = F.mse_loss(w2, w + ctrl)
+    ke, ke2 = 0.5 * (w ** 2).sum(1), 0.5 * (w2 ** 2).sum(1)
+    en = F.mse_loss(ke2, ke + 0.5 * (actions ** 2).sum(1) * 0.01)
+    ones = torch.ones(states.shape[0])
+    qn = F.mse_loss(states[:, :4].norm(dim=1), ones) + F.mse_loss(next_states[:, :4].norm(dim=1), ones)
+    return (mom + en + qn) * weight, [mom, en, qn]
+
+
+class AdamState:
+    """torch.optim.Adam defaults (betas .9/.999, eps 1e-8, no weight decay), written out."""
+
+    def __init__(self, params):
+        self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.t = {k: 0 for k in params}
+
+    def step(self, params, grads, lr=LR, b1=0.9, b2=0.999, eps=1e-8):
+        with torch.no_grad():
+            for k, g in grads.items():
+                if g is None:  # parameters outside the loss graph (value head) are skipped by torch too
+                    continue
+                self.t[k] += 1
+                t = self.t[k]
+                self.m[k].mul_(b1).add_(g, alpha=1 - b1)
+                self.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+                bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+                denom = (self.v[k].sqrt() / math.sqrt(bc2)).add_(eps)
+                params[k].addcdiv_(self.m[k], denom, value=-lr / bc1)
+
+
+class SacOracle:
+    """State of one SAC learner in reference parameterisation."""
+
+    def __init__(self, policy, q1, q2, batch_pe=False):
+        self.P = {k: v.clone().requires_grad_(True) for k, v in policy.items()}
+        self.Q = [{k: v.clone().requires_grad_(True) for k, v in q.items()} for q in (q1, q2)]
+        self.TQ = [{k: v.clone() for k, v in q.items()} for q in (q1, q2)]
+        self.opt_p = AdamState(self.P)
+        self.opt_q = [AdamState(q) for q in self.Q]
+        self.batch_pe = batch_pe
+
+    def update(self, s, a, r, s2, d, eps_next, eps_new):
+        """One _update_sac (agent/...:950-1016) with the two Gaussian draws supplied."""
+        with torch.no_grad():
+            m2, ls2 = actor_forward(self.P, s2, self.batch_pe)
+            a2 = m2 + torch.exp(ls2) * eps_next
+            tq = torch.min(critic_forward(self.TQ[0], s2, a2), critic_forward(self.TQ[1], s2, a2))
+            y = r + GAMMA * (1 - d) * tq
+        losses = []
+        for i in range(2):
+            q = critic_forward(self.Q[i], s, a)
+            loss = F.mse_loss(q, y)
+            grads = torch.autograd.grad(loss, list(self.Q[i].values()))
+            self.opt_q[i].step(self.Q[i], dict(zip(self.Q[i].keys(), grads)))
+            losses.append(float(loss.detach()))
+        mean, ls = actor_forward(self.P, s, self.batch_pe)
+        std = torch.exp(ls)
+        a_new = mean + std * eps_new
+        logp = (-((a_new - mean) ** 2) / (2 * std ** 2) - ls - math.log(math.sqrt(2 * math.pi))).sum(-1)
+        qn = torch.min(critic_forward(self.Q[0], s, a_new), critic_forward(self.Q[1], s, a_new))
+        ploss = -(qn - ALPHA * logp).mean()
+        names = list(self.P.keys())
+        grads = torch.autograd.grad(ploss, [self.P[k] for k in names], allow_unused=True)
+        self.opt_p.step(self.P, dict(zip(names, grads)))
+        with torch.no_grad():
+            for i in range(2):
+                for k in self.TQ[i]:
+                    self.TQ[i][k].copy_(TAU * self.Q[i][k] + (1 - TAU) * self.TQ[i][k])
+        return losses[0], losses[1], float(ploss.detach())
+
+
+# --- the BASELINE.json "256x256 MLP" family (legacy SACAgent shapes; not in the shipped reference code):
+#     actor obs->256->256->2A ReLU, critics (obs+A)->256->256->1 ReLU, same update rule.
+def mlp_actor_forward(P, obs):
+    h = F.relu(obs @ P["0.weight"].T + P["0.bias"])
+    h = F.relu(h @ P["2.weight"].T + P["2.bias"])
+    out = h @ P["4.weight"].T + P["4.bias"]
+    a_dim = out.shape[1] // 2
+    return out[:, :a_dim], torch.clamp(out[:, a_dim:], -20, 2)
+
+
+def mlp_critic_forward(Q, s, a):
+    h = F.relu(torch.cat([s, a], -1) @ Q["0.weight"].T + Q["0.bias"])
+    h = F.relu(h @ Q["2.weight"].T + Q["2.bias"])
+    return (h @ Q["4.weight"].T + Q["4.bias"]).squeeze(-1)
