@@ -140,6 +140,100 @@ int tvc_env_info(tvc_env* env, float* info_dev, void* stream);
  * reference, env/...:530-533): number of decrements until empty / until < 0.8 / until <= 0.1. */
 int tvc_env_fuel_thresholds(const tvc_env* env, int32_t* k_empty, int32_t* k_coast, int32_t* k_low);
 
+/* ------------------------------------------------------------------ SAC learner (K3-K7, K11) */
+
+typedef struct tvc_sac tvc_sac;
+
+/* Network families:
+ *   0 = the shipped reference shapes (agent/multi_algorithm_agent.py:587-627): actor =
+ *       TransformerPolicyNetwork at sequence length 1 (== embed, +PE, n_layers x {V-proj, O-proj, +res,
+ *       LN, FFN GELU, +res, LN}, LN, policy head d->h1->h2->2A with GELU+LN); critics
+ *       (obs+A)->c1->c2->1 with GELU+LN.  Dead compute of the reference (Q/K projections, value head;
+ *       SURVEY F8) is not executed; those tensors stay with the caller for checkpoints.
+ *   1 = the "256x256 MLP" of BASELINE.json / the legacy SACAgent: actor obs->m1->m2->2A ReLU,
+ *       critics (obs+A)->c1->c2->1 ReLU. */
+typedef struct tvc_sac_cfg {
+    int32_t obs_dim, act_dim;       /* 10, 2 */
+    int32_t family;
+    int32_t d_model, n_layers, ff_dim, head1, head2; /* family 0: 256, 4, 512, 512, 512 */
+    int32_t mlp1, mlp2;             /* family 1 actor hidden: 256, 256 */
+    int32_t critic1, critic2;       /* 512, 256 (family 0) or 256, 256 (family 1) */
+    int32_t batch_size;             /* update batch rows (256) */
+    int32_t max_act_rows;           /* largest batch tvc_sac_act will see */
+    int32_t pe_rows;                /* 1: PE(0) on every row (== reference at B=1); >1: the reference's
+                                       batch-row-indexed table, rows >= pe_rows reuse the last */
+    float gamma, alpha, tau, lr;    /* 0.99, 0.2, 0.005, 3e-4  (agent/...:971,998,1005,623-625) */
+    float adam_b1, adam_b2, adam_eps; /* torch.optim.Adam defaults */
+    int32_t _pad;
+} tvc_sac_cfg;
+
+void tvc_sac_default_cfg(tvc_sac_cfg* cfg, int32_t family);
+
+/* Parameter table (host-only queries, no GPU needed).  One flat fp32 buffer holds
+ * [policy | q1 | q2 | target_q1 | target_q2]; gradients / Adam moments cover the trainable prefix
+ * [policy | q1 | q2].  Tensor names follow the reference's state_dict keys where a 1:1 tensor exists
+ * ("policy.input_embedding.weight", "q1.0.weight", ...); "policy.layers.<l>.v_proj.*" are rows
+ * 2d..3d of the reference's self_attn.in_proj_*. */
+int64_t tvc_sac_param_count(const tvc_sac_cfg* cfg);      /* floats in the full parameter buffer */
+int64_t tvc_sac_trainable_count(const tvc_sac_cfg* cfg);  /* floats in grads / adam_m / adam_v */
+int32_t tvc_sac_num_tensors(const tvc_sac_cfg* cfg);
+int tvc_sac_tensor_info(const tvc_sac_cfg* cfg, int32_t idx, char* name, int32_t name_cap, int64_t* offset,
+                        int32_t* rows, int32_t* cols);
+
+/* _create_sac_agent (agent/...:587-627).  The four flat buffers are caller-owned device memory
+ * (torch tensors): params[param_count], grads / adam_m / adam_v [trainable_count].  pe_table_host:
+ * float[pe_rows, d_model] (family 0) or NULL. */
+int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params_dev, float* grads_dev, float* adam_m_dev,
+                   float* adam_v_dev, const float* pe_table_host, tvc_sac** out);
+void tvc_sac_destroy(tvc_sac* sac);
+
+/* Policy part of get_action (agent/...:765-789) for n rows: mean/log_std (clamped to [-20,2]) and
+ * action = clamp(mean + exp(log_std) * eps, -1, 1); eps_dev NULL = deterministic (action = clamp(mean)).
+ * obs_dev float[n,obs]; act_dev float[n,A]; mean_dev / logstd_dev float[n,A] or NULL. */
+int tvc_sac_act(tvc_sac* sac, const float* obs_dev, int32_t n, const float* eps_dev, float* act_dev, float* mean_dev,
+                float* logstd_dev, void* stream);
+
+/* One _update_sac (agent/...:950-1016) on a batch of batch_size rows, in four phases so that the caller can
+ * all-reduce gradients between them (data parallel, K10):
+ *   critic_grads: target y, q1/q2 forward + backward -> grads[q1|q2], losses[0..1]
+ *   critic_apply: Adam on q1, q2 (gradients multiplied by grad_scale first, e.g. 1/world_size)
+ *   actor_grads : policy forward, q(s, a_new) through the UPDATED critics, backward -> grads[policy], losses[2]
+ *   actor_apply : Adam on the policy, Polyak update of both targets
+ * s, s2 float[B,obs]; a float[B,A]; r, d float[B] (d = done as 0/1 float; the reference's BoolTensor
+ * `dones` raises inside its update); eps_next / eps_new float[B,A] standard-normal draws;
+ * losses_dev float[4] = q1_loss, q2_loss, policy_loss, physics_loss (PhysicsInformedLoss, agent/...:236-285,
+ * reported only). */
+int tvc_sac_critic_grads(tvc_sac* sac, const float* s, const float* a, const float* r, const float* s2, const float* d,
+                         const float* eps_next, float* losses_dev, void* stream);
+int tvc_sac_critic_apply(tvc_sac* sac, float grad_scale, void* stream);
+int tvc_sac_actor_grads(tvc_sac* sac, const float* s, const float* eps_new, float* losses_dev, void* stream);
+int tvc_sac_actor_apply(tvc_sac* sac, float grad_scale, void* stream);
+/* all four phases back to back (single GPU) */
+int tvc_sac_update(tvc_sac* sac, const float* s, const float* a, const float* r, const float* s2, const float* d,
+                   const float* eps_next, const float* eps_new, float* losses_dev, void* stream);
+
+/* critic forward q1(s,a), q2(s,a) for n <= batch_size rows (tests / diagnostics): q_dev float[2,n] */
+int tvc_sac_q_values(tvc_sac* sac, const float* s, const float* a, int32_t n, int32_t use_target, float* q_dev, void* stream);
+
+/* ------------------------------------------------------------------ replay buffer (K8) */
+
+typedef struct tvc_replay tvc_replay;
+/* Device-resident uniform replay (BASELINE.json: capacity 1M, batch 256; the shipped reference has none,
+ * SURVEY a21; legacy surface: store_transition / len(replay_buffer), tests/test_agent.py:99-108).
+ * Row = {s[obs], a[A], r, s2[obs], d} stored row-major ("array of rows": a sampled batch is 256 random
+ * 96-byte rows, each one contiguous). */
+int tvc_replay_create(int64_t capacity, int32_t obs_dim, int32_t act_dim, int32_t device, tvc_replay** out);
+void tvc_replay_destroy(tvc_replay* rb);
+int64_t tvc_replay_size(const tvc_replay* rb);
+/* append n transitions (ring overwrite). done = terminated|truncated as uint8 flags. */
+int tvc_replay_insert(tvc_replay* rb, const float* s, const float* a, const float* r, const float* s2,
+                      const uint8_t* term, const uint8_t* trunc, int32_t n, void* stream);
+/* uniform sample of `batch` rows with Philox4x32-10 keyed by (seed, counter); counter == UINT64_MAX uses an
+ * auto-incrementing device-resident counter (so a captured hipGraph draws fresh rows at every replay).
+ * Head / size live on the device too; tvc_replay_size() synchronises.  Outputs are dense device arrays. */
+int tvc_replay_sample(tvc_replay* rb, int32_t batch, uint64_t seed, uint64_t counter, float* s, float* a, float* r,
+                      float* s2, float* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,7 +104,9 @@ class AdamState:
 class SacOracle:
     """State of one SAC learner in reference parameterisation."""
 
-    def __init__(self, policy, q1, q2, batch_pe=False):
+    def __init__(self, policy, q1, q2, batch_pe=False, actor_fn=None, critic_fn=None):
+        self.actor_fn = actor_fn or (lambda P, x: actor_forward(P, x, batch_pe))
+        self.critic_fn = critic_fn or critic_forward
         self.P = {k: v.clone().requires_grad_(True) for k, v in policy.items()}
         self.Q = [{k: v.clone().requires_grad_(True) for k, v in q.items()} for q in (q1, q2)]
         self.TQ = [{k: v.clone() for k, v in q.items()} for q in (q1, q2)]
@@ -115,22 +117,22 @@ class SacOracle:
     def update(self, s, a, r, s2, d, eps_next, eps_new):
         """One _update_sac (agent/...:950-1016) with the two Gaussian draws supplied."""
         with torch.no_grad():
-            m2, ls2 = actor_forward(self.P, s2, self.batch_pe)
+            m2, ls2 = self.actor_fn(self.P, s2)
             a2 = m2 + torch.exp(ls2) * eps_next
-            tq = torch.min(critic_forward(self.TQ[0], s2, a2), critic_forward(self.TQ[1], s2, a2))
+            tq = torch.min(self.critic_fn(self.TQ[0], s2, a2), self.critic_fn(self.TQ[1], s2, a2))
             y = r + GAMMA * (1 - d) * tq
         losses = []
         for i in range(2):
-            q = critic_forward(self.Q[i], s, a)
+            q = self.critic_fn(self.Q[i], s, a)
             loss = F.mse_loss(q, y)
             grads = torch.autograd.grad(loss, list(self.Q[i].values()))
             self.opt_q[i].step(self.Q[i], dict(zip(self.Q[i].keys(), grads)))
             losses.append(float(loss.detach()))
-        mean, ls = actor_forward(self.P, s, self.batch_pe)
+        mean, ls = self.actor_fn(self.P, s)
         std = torch.exp(ls)
         a_new = mean + std * eps_new
         logp = (-((a_new - mean) ** 2) / (2 * std ** 2) - ls - math.log(math.sqrt(2 * math.pi))).sum(-1)
-        qn = torch.min(critic_forward(self.Q[0], s, a_new), critic_forward(self.Q[1], s, a_new))
+        qn = torch.min(self.critic_fn(self.Q[0], s, a_new), self.critic_fn(self.Q[1], s, a_new))
         ploss = -(qn - ALPHA * logp).mean()
         names = list(self.P.keys())
         grads = torch.autograd.grad(ploss, [self.P[k] for k in names], allow_unused=True)

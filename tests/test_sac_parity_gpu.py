@@ -1,0 +1,216 @@
+"""HIP SAC learner (through the C ABI) vs the eager-PyTorch restatement (oracle/sac_torch.py, itself pinned
+against the reference's own code) and vs the reference goldens (data only).
+
+Tolerances (fp32 on both sides; MFMA f32 is an exact k-ordered fma chain, so differences are summation order):
+  forward outputs |diff| <= 2e-4 abs, losses <= 2e-4 rel, parameters after k Adam steps <= 2*lr*k*1.05 per element
+  (an element whose gradient is ~0 moves by lr per step in either direction), < 2 % of elements off by > 2e-5, and <= 2e-5 relative on the
+  per-tensor |.|-sum digest."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sac_torch as st
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _recipe():
+    spec = importlib.util.spec_from_file_location("gen_sac_golden", os.path.join(HERE, "golden", "gen_sac_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def ref_nets(rec, meta, rng):
+    nets = {}
+    for k in ("policy", "q1", "q2"):
+        named = [(n, tuple(s)) for n, s in meta["nets"][k]]
+        nets[k] = {n: torch.from_numpy(v) for n, v in rec.fill_params(named, rng).items()}
+    return nets
+
+
+def load_into_native(sac, nets):
+    sac.load_reference_state("policy", nets["policy"])
+    for k in ("q1", "q2"):
+        sac.load_reference_state(k, nets[k])
+        sac.load_reference_state("target_" + k, nets[k])
+
+
+def cuda(*xs):
+    return [torch.as_tensor(x).cuda().contiguous() for x in xs]
+
+
+@pytest.mark.parametrize("batch_pe", [True, False])
+def test_reference_shapes_forward_and_three_updates(batch_pe):
+    from tvc_ai_amd.agent import NativeSAC, sac_cfg
+    torch.set_num_threads(8)
+    rec = _recipe()
+    meta = json.load(open(os.path.join(HERE, "golden", "sac_ref_meta.json")))
+    g = np.load(os.path.join(HERE, "golden", "sac_ref.npz"))
+    rng = np.random.default_rng(meta["seed"])
+    nets = ref_nets(rec, meta, rng)
+    B = 256
+    sac = NativeSAC(sac_cfg(0, batch_size=B, max_act_rows=1024, pe_rows=B if batch_pe else 1), init=False)
+    load_into_native(sac, nets)
+    s, a, r, s2, d = [torch.from_numpy(x) for x in rec.make_batch(rng)]
+    sg, ag, rg, s2g, dg = cuda(s, a, r, s2, d)
+
+    # forward: actor (deterministic act) and critics
+    act, mean, ls = sac.act(sg, None)
+    with torch.no_grad():
+        m_ref, ls_ref = st.actor_forward(nets["policy"], s, batch_pe=batch_pe)
+        q_ref = torch.stack([st.critic_forward(nets["q1"], s, a), st.critic_forward(nets["q2"], s, a)])
+    np.testing.assert_allclose(mean.cpu().numpy(), m_ref.numpy(), atol=2e-4, rtol=0)
+    np.testing.assert_allclose(ls.cpu().numpy(), ls_ref.numpy(), atol=2e-4, rtol=0)
+    np.testing.assert_allclose(act.cpu().numpy(), m_ref.clamp(-1, 1).numpy(), atol=2e-4, rtol=0)
+    q = sac.q_values(sg, ag)
+    np.testing.assert_allclose(q.cpu().numpy(), q_ref.numpy(), atol=2e-4, rtol=2e-5)
+    if batch_pe:  # the reference's own numbers (batch-row positional encoding)
+        np.testing.assert_allclose(mean.cpu().numpy(), g["fwd_mean_batchpe"], atol=2e-4, rtol=0)
+        np.testing.assert_allclose(q[0].cpu().numpy(), g["fwd_q1"], atol=2e-4, rtol=2e-5)
+    else:
+        np.testing.assert_allclose(mean[:1].cpu().numpy(), g["fwd_mean_pe0_first8"][:1], atol=2e-4, rtol=0)
+
+    # three updates with the captured noise
+    orc = st.SacOracle(nets["policy"], nets["q1"], nets["q2"], batch_pe=batch_pe)
+    for u in range(3):
+        e1 = torch.from_numpy(rng.standard_normal((B, 2)).astype(np.float32))
+        e2 = torch.from_numpy(rng.standard_normal((B, 2)).astype(np.float32))
+        if u > 0:
+            s, a, r, s2, d = [torch.from_numpy(x) for x in rec.make_batch(rng)]
+            sg, ag, rg, s2g, dg = cuda(s, a, r, s2, d)
+        l_ref = orc.update(s, a, r, s2, d, e1, e2)
+        pl_ref, _ = st.physics_loss(s, a, s2)
+        losses = sac.update(sg, ag, rg, s2g, dg, *cuda(e1, e2)).cpu().numpy()
+        np.testing.assert_allclose(losses[:3], l_ref, rtol=2e-4, err_msg=f"update {u}")
+        np.testing.assert_allclose(losses[3], float(pl_ref), rtol=1e-4)
+        if batch_pe:
+            np.testing.assert_allclose(losses[:3], g["losses"][u, :3], rtol=2e-4, err_msg=f"update {u} vs reference golden")
+        # parameters
+        # Adam's first steps are sign-like (lr * g / (|g| + eps)): an element whose gradient is ~0 can come out
+        # at +lr on one side and -lr on the other, so single elements may differ by 2 lr per step; almost all
+        # elements must agree far better than that
+        tol = 2 * st.LR * (u + 1) * 1.05
+        groups = {"policy": orc.P, "q1": orc.Q[0], "q2": orc.Q[1], "target_q1": orc.TQ[0], "target_q2": orc.TQ[1]}
+        for net, ref_params in groups.items():
+            mine = sac.export_reference_state(net)
+            for k, v in ref_params.items():
+                if net == "policy" and (k.startswith("value_head") or k.startswith("pos_encoding")):
+                    continue
+                got, want = mine[k], v.detach()
+                if "in_proj" in k:
+                    got, want = got[512:], want[512:]
+                adiff = (got - want).abs()
+                diff = adiff.max().item()
+                assert diff <= tol, (u, net, k, diff)
+                assert (adiff > 2e-5).float().mean().item() < 0.02, (u, net, k, "too many elements off")
+                sa, sb = got.abs().sum().item(), want.abs().sum().item()
+                assert abs(sa - sb) <= 2e-5 * max(sb, 1.0) + 1e-6, (u, net, k, sa, sb)
+    sac.close()
+
+
+def test_mlp_family_updates():
+    """BASELINE.json's 256x256 ReLU MLP actor/critics (legacy SACAgent shapes), same update rule."""
+    from tvc_ai_amd.agent import NativeSAC, sac_cfg
+    torch.manual_seed(3)
+    B = 256
+    sac = NativeSAC(sac_cfg(1, batch_size=B, max_act_rows=512), seed=5)
+    P = {k[len("policy."):]: sac.view(k).cpu().clone() for k, *_ in sac.table if k.startswith("policy.")}
+    Q1 = {k[len("q1."):]: sac.view(k).cpu().clone() for k, *_ in sac.table if k.startswith("q1.")}
+    Q2 = {k[len("q2."):]: sac.view(k).cpu().clone() for k, *_ in sac.table if k.startswith("q2.")}
+    orc = st.SacOracle(P, Q1, Q2, actor_fn=st.mlp_actor_forward, critic_fn=st.mlp_critic_forward)
+    for u in range(4):
+        s = torch.randn(B, 10) * 0.5
+        s2 = s + 0.05 * torch.randn(B, 10)
+        a = torch.rand(B, 2) * 2 - 1
+        r = torch.randn(B) * 30 + 50
+        d = (torch.rand(B) < 0.1).float()
+        e1, e2 = torch.randn(B, 2), torch.randn(B, 2)
+        l_ref = orc.update(s, a, r, s2, d, e1, e2)
+        losses = sac.update(*cuda(s, a, r, s2, d, e1, e2)).cpu().numpy()
+        np.testing.assert_allclose(losses[:3], l_ref, rtol=3e-4, err_msg=f"update {u}")
+    tol = 2 * st.LR * 4 * 1.05
+    for name, ref in (("policy.", orc.P), ("q1.", orc.Q[0]), ("target_q2.", orc.TQ[1])):
+        for k, v in ref.items():
+            assert (sac.view(name + k).cpu() - v.detach()).abs().max().item() <= tol, (name, k)
+    sac.close()
+
+
+def test_act_large_ragged_batch_and_sampling():
+    from tvc_ai_amd.agent import NativeSAC, sac_cfg
+    n = 5000 + 37
+    sac = NativeSAC(sac_cfg(0, batch_size=64, max_act_rows=8192), seed=11)
+    P = sac.export_reference_state("policy")
+    obs = torch.randn(n, 10) * 0.5
+    eps = torch.randn(n, 2)
+    act, mean, ls = sac.act(*cuda(obs), cuda(eps)[0])
+    with torch.no_grad():
+        m_ref, ls_ref = st.actor_forward(P, obs, batch_pe=False)
+    np.testing.assert_allclose(mean.cpu().numpy(), m_ref.numpy(), atol=3e-4, rtol=0)
+    np.testing.assert_allclose(ls.cpu().numpy(), ls_ref.numpy(), atol=3e-4, rtol=0)
+    a_ref = (m_ref + torch.exp(ls_ref) * eps).clamp(-1, 1)
+    np.testing.assert_allclose(act.cpu().numpy(), a_ref.numpy(), atol=1e-3, rtol=0)
+    with pytest.raises(Exception):
+        sac.act(torch.zeros(9000, 10).cuda(), None)  # > max_act_rows must fail loudly
+    sac.close()
+
+
+def test_replay_buffer_roundtrip_and_uniformity():
+    from tvc_ai_amd.agent import ReplayBuffer
+    rb = ReplayBuffer(1000, 10, 2, seed=7)
+    assert len(rb) == 0
+    n = 300
+    rows = []
+    for k in range(5):  # 1500 rows into capacity 1000: ring overwrite
+        s = torch.full((n, 10), float(k)).cuda() + torch.arange(n).view(n, 1).cuda() * 1e-3
+        a = torch.rand(n, 2).cuda()
+        r = torch.arange(n).float().cuda() + 1000 * k
+        s2 = s + 0.5
+        term = (torch.arange(n) % 7 == 0).to(torch.uint8).cuda()
+        trunc = (torch.arange(n) % 11 == 0).to(torch.uint8).cuda()
+        rb.insert(s, a, r, s2, term, trunc)
+        rows.append((s, a, r, s2, term | trunc))
+    assert len(rb) == 1000
+    s, a, r, s2, d = rb.sample(4096, counter=3)
+    r_np = r.cpu().numpy()
+    assert r_np.min() >= 1000 * 1 + 200  # rows 0..499 (k=0 and most of k=1) were overwritten
+    # each sampled row is internally consistent
+    k = (r_np // 1000).astype(int)
+    i = (r_np % 1000).astype(int)
+    np.testing.assert_allclose(s[:, 0].cpu().numpy(), k + i * 1e-3, atol=1e-5)
+    np.testing.assert_allclose(s2.cpu().numpy(), s.cpu().numpy() + 0.5, atol=1e-6)
+    np.testing.assert_array_equal(d.cpu().numpy(), ((i % 7 == 0) | (i % 11 == 0)).astype(np.float32))
+    # same (seed, counter) -> same rows; device counter advances
+    s_again, *_ = rb.sample(4096, counter=3)
+    assert torch.equal(s, s_again)
+    x1 = rb.sample(256)[2].clone()
+    x2 = rb.sample(256)[2].clone()
+    assert not torch.equal(x1, x2)
+    # roughly uniform over the 1000 live rows
+    _, _, rr, _, _ = rb.sample(200000, counter=9)
+    cnt = np.bincount(((rr.cpu().numpy() // 1000) * 300 + rr.cpu().numpy() % 1000).astype(int))
+    live = cnt[cnt > 0]
+    assert len(live) == 1000 and live.min() > 120 and live.max() < 290
+    rb.close()
+
+
+def test_agent_surface_update_accepts_bool_dones():
+    """MultiAlgorithmAgent drop-in: scripts/train.py:577-584 builds B=1 tensors with a BoolTensor `dones`."""
+    from tvc_ai_amd.agent import MultiAlgorithmAgent
+    agent = MultiAlgorithmAgent(10, 2, {"tvc_native": {"batch_size": 1, "max_act_rows": 16}, "physics_informed": {"enabled": True}})
+    obs = torch.randn(1, 10)
+    action, info = agent.get_action(obs)
+    assert isinstance(action, np.ndarray) and action.shape == (1, 2) and np.all(np.abs(action) <= 1)
+    assert info["algorithm"] == "sac" and info["mean"].shape == (1, 2)
+    batch = {"states": obs, "actions": torch.from_numpy(action), "rewards": torch.tensor([1.5]),
+             "next_states": obs + 0.1, "dones": torch.BoolTensor([False])}
+    out = agent.update(batch)
+    assert set(out) >= {"q1_loss", "q2_loss", "policy_loss"} and all(np.isfinite(v) for v in out.values()), out
+    assert agent.select_algorithm() == "sac"
+    agent.update_performance("sac", 12.0)
+    assert list(agent.performance_history["sac"]) == [12.0]

@@ -56,6 +56,42 @@ SIGNATURES = {
 }
 
 
+class SacCfg(C.Structure):
+    """Mirror of `struct tvc_sac_cfg` (include/tvc_native.h)."""
+    _fields_ = [
+        ("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("family", C.c_int32),
+        ("d_model", C.c_int32), ("n_layers", C.c_int32), ("ff_dim", C.c_int32), ("head1", C.c_int32), ("head2", C.c_int32),
+        ("mlp1", C.c_int32), ("mlp2", C.c_int32), ("critic1", C.c_int32), ("critic2", C.c_int32),
+        ("batch_size", C.c_int32), ("max_act_rows", C.c_int32), ("pe_rows", C.c_int32),
+        ("gamma", C.c_float), ("alpha", C.c_float), ("tau", C.c_float), ("lr", C.c_float),
+        ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("_pad", C.c_int32),
+    ]
+
+
+SIGNATURES.update({
+    "tvc_sac_default_cfg": (None, [C.POINTER(SacCfg), C.c_int32]),
+    "tvc_sac_param_count": (C.c_int64, [C.POINTER(SacCfg)]),
+    "tvc_sac_trainable_count": (C.c_int64, [C.POINTER(SacCfg)]),
+    "tvc_sac_num_tensors": (C.c_int32, [C.POINTER(SacCfg)]),
+    "tvc_sac_tensor_info": (C.c_int, [C.POINTER(SacCfg), C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int64),
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "tvc_sac_create": (C.c_int, [C.POINTER(SacCfg), C.c_int32, _VP, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
+    "tvc_sac_destroy": (None, [_VP]),
+    "tvc_sac_act": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP]),
+    "tvc_sac_critic_grads": (C.c_int, [_VP] + [_VP] * 8),
+    "tvc_sac_critic_apply": (C.c_int, [_VP, C.c_float, _VP]),
+    "tvc_sac_actor_grads": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),
+    "tvc_sac_actor_apply": (C.c_int, [_VP, C.c_float, _VP]),
+    "tvc_sac_update": (C.c_int, [_VP] + [_VP] * 9),
+    "tvc_sac_q_values": (C.c_int, [_VP, _VP, _VP, C.c_int32, C.c_int32, _VP, _VP]),
+    "tvc_replay_create": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_VP)]),
+    "tvc_replay_destroy": (None, [_VP]),
+    "tvc_replay_size": (C.c_int64, [_VP]),
+    "tvc_replay_insert": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int32, _VP]),
+    "tvc_replay_sample": (C.c_int, [_VP, C.c_int32, C.c_uint64, C.c_uint64, _VP, _VP, _VP, _VP, _VP, _VP]),
+})
+
+
 def lib_path():
     return _build.LIB
 

@@ -1,0 +1,421 @@
+"""Host-side mirror of the reference agent surface over the HIP SAC learner (csrc/tvc_sac.hip).
+
+* ``NativeSAC``           -- flat parameter / gradient / Adam buffers (torch tensors) + the C handle:
+                             act(), update(), reference state_dict import/export.
+* ``ReplayBuffer``        -- device-resident uniform replay (csrc/tvc_replay.hip).
+* ``MultiAlgorithmAgent`` -- same constructor and methods as the reference class
+                             (agent/multi_algorithm_agent.py:419-1179) for the SAC path.
+
+Nothing here computes a forward / backward pass: torch only owns memory, RNG draws and checkpoints.
+"""
+import ctypes as C
+import logging
+import math
+from collections import deque
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+
+SacCfg = nat.SacCfg
+
+AUTO_COUNTER = (1 << 64) - 1
+
+
+def positional_encoding_table(rows: int, d_model: int) -> torch.Tensor:
+    """PositionalEncoding.pe rows 0..rows-1 (agent/multi_algorithm_agent.py:93-102), a constant buffer."""
+    pe = torch.zeros(rows, d_model)
+    position = torch.arange(0, rows, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-np.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe.contiguous()
+
+
+def sac_cfg(family: int = 0, **over) -> SacCfg:
+    cfg = SacCfg()
+    nat.load().tvc_sac_default_cfg(C.byref(cfg), family)
+    for k, v in over.items():
+        if not hasattr(cfg, k):
+            raise KeyError(f"unknown tvc_sac_cfg field {k!r}")
+        setattr(cfg, k, v)
+    return cfg
+
+
+def tensor_table(cfg: SacCfg):
+    """[(name, offset, rows, cols)] of the flat parameter buffer (host-only query)."""
+    L = nat.load()
+    n = L.tvc_sac_num_tensors(C.byref(cfg))
+    if n < 0:
+        nat.check(n)
+    out = []
+    name = C.create_string_buffer(128)
+    off, rows, cols = C.c_int64(), C.c_int32(), C.c_int32()
+    for i in range(n):
+        nat.check(L.tvc_sac_tensor_info(C.byref(cfg), i, name, 128, C.byref(off), C.byref(rows), C.byref(cols)))
+        out.append((name.value.decode(), off.value, rows.value, cols.value))
+    return out
+
+
+def _ref_to_native_name(net: str, ref_key: str):
+    """reference state_dict key -> (native tensor name, row slice or None)."""
+    if net == "policy":
+        k = ref_key.replace("transformer_encoder.layers.", "layers.")
+        if k.endswith("self_attn.in_proj_weight") or k.endswith("self_attn.in_proj_bias"):
+            base = k[:k.index("self_attn")]
+            return f"policy.{base}v_proj.{'weight' if k.endswith('weight') else 'bias'}", "v_rows"
+        k = k.replace("self_attn.out_proj", "out_proj")
+        return f"policy.{k}", None
+    return f"{net}.{ref_key}", None
+
+
+class NativeSAC:
+    """SAC learner state on one GPU.  Parameters live in ONE flat fp32 torch tensor
+    [policy | q1 | q2 | target_q1 | target_q2]; grads / Adam moments cover [policy | q1 | q2]."""
+
+    def __init__(self, cfg: Optional[SacCfg] = None, device="cuda:0", seed: int = 0, init: bool = True, **over):
+        self.L = nat.load()
+        self.cfg = cfg if cfg is not None else sac_cfg(**over)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise nat.TvcError("NativeSAC needs a GPU device: there is no CPU fallback")
+        self.table = tensor_table(self.cfg)
+        self.index = {n: (o, r, c) for n, o, r, c in self.table}
+        n_all = self.L.tvc_sac_param_count(C.byref(self.cfg))
+        n_tr = self.L.tvc_sac_trainable_count(C.byref(self.cfg))
+        self.params = torch.zeros(n_all, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(n_tr, dtype=torch.float32, device=self.device)
+        self.adam_m = torch.zeros(n_tr, dtype=torch.float32, device=self.device)
+        self.adam_v = torch.zeros(n_tr, dtype=torch.float32, device=self.device)
+        self.losses = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.n_policy = self.index["q1." + self._critic_first()][0]
+        self.n_critic = (n_tr - self.n_policy) // 2
+        self.passive = {}  # reference tensors the SAC path never touches (Q/K projection rows, value head)
+        pe = positional_encoding_table(self.cfg.pe_rows, self.cfg.d_model) if self.cfg.family == 0 else None
+        self._pe_host = pe
+        self._h = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        nat.check(self.L.tvc_sac_create(C.byref(self.cfg), dev_index, self.params.data_ptr(), self.grads.data_ptr(),
+                                        self.adam_m.data_ptr(), self.adam_v.data_ptr(),
+                                        pe.data_ptr() if pe is not None else None, C.byref(self._h)))
+        if init:
+            self.init_parameters(seed)
+
+    def _critic_first(self):
+        return "0.weight"
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.L.tvc_sac_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    # -- parameters
+    def view(self, name: str) -> torch.Tensor:
+        off, rows, cols = self.index[name]
+        return self.params[off:off + rows * cols].view(rows, cols) if cols > 1 else self.params[off:off + rows]
+
+    def grad_view(self, name: str) -> torch.Tensor:
+        off, rows, cols = self.index[name]
+        return self.grads[off:off + rows * cols].view(rows, cols) if cols > 1 else self.grads[off:off + rows]
+
+    def init_parameters(self, seed: int = 0):
+        """The reference's initialisation: policy Linear layers orthogonal(gain sqrt 2) + zero bias
+        (agent/...:185-190), LayerNorm (1, 0), critics torch's default nn.Linear init; targets = copies."""
+        g = torch.Generator().manual_seed(seed)
+        for name, off, rows, cols in self.table:
+            if name.startswith("target_"):
+                continue
+            t = torch.empty(rows, cols) if cols > 1 else torch.empty(rows)
+            is_ln = cols == 1 and name.endswith("weight")
+            if is_ln:
+                t.fill_(1.0)
+            elif cols == 1:
+                if name.startswith("policy.") or self._is_ln_bias(name):
+                    t.zero_()
+                else:  # nn.Linear default bias: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                    fan_in = self.index[name.replace("bias", "weight")][2]
+                    t.uniform_(-1 / math.sqrt(fan_in), 1 / math.sqrt(fan_in), generator=g)
+            elif name.startswith("policy."):
+                torch.nn.init.orthogonal_(t, gain=math.sqrt(2), generator=g)
+            else:  # kaiming_uniform(a=sqrt 5) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+                t.uniform_(-1 / math.sqrt(cols), 1 / math.sqrt(cols), generator=g)
+            self.view(name).copy_(t)
+        self.sync_targets()
+
+    def _is_ln_bias(self, name):
+        w = name.replace("bias", "weight")
+        return w in self.index and self.index[w][2] == 1
+
+    def sync_targets(self):
+        n0, nc = self.n_policy, self.n_critic
+        self.params[n0 + 2 * nc:n0 + 4 * nc].copy_(self.params[n0:n0 + 2 * nc])
+
+    def load_named(self, tensors: Dict[str, torch.Tensor]):
+        """native names -> values"""
+        for k, v in tensors.items():
+            dst = self.view(k)
+            dst.copy_(torch.as_tensor(v, dtype=torch.float32).reshape(dst.shape))
+
+    def load_reference_state(self, net: str, state_dict: Dict[str, torch.Tensor]):
+        """Import one reference net's state_dict (net in policy, q1, q2, target_q1, target_q2)."""
+        d = self.cfg.d_model
+        for k, v in state_dict.items():
+            v = torch.as_tensor(v, dtype=torch.float32)
+            if net == "policy" and (k.startswith("value_head") or k.startswith("pos_encoding")):
+                self.passive[f"{net}.{k}"] = v.clone().cpu()
+                continue
+            name, sl = _ref_to_native_name(net, k)
+            if sl == "v_rows":
+                self.passive[f"{net}.{k}"] = v.clone().cpu()  # keeps the dead Q/K rows for export
+                v = v[2 * d:3 * d]
+            if name not in self.index:
+                raise KeyError(f"{net}.{k} has no native tensor ({name})")
+            self.view(name).copy_(v.reshape(self.view(name).shape))
+
+    def export_reference_state(self, net: str) -> Dict[str, torch.Tensor]:
+        """Reference-keyed state_dict of one net (checkpoint compatibility, agent/...:1098-1141)."""
+        d = self.cfg.d_model
+        out = {}
+        if net == "policy" and self.cfg.family == 0:
+            out["input_embedding.weight"] = self.view("policy.input_embedding.weight").cpu().clone()
+            out["input_embedding.bias"] = self.view("policy.input_embedding.bias").cpu().clone()
+            out["pos_encoding.pe"] = self.passive.get("policy.pos_encoding.pe",
+                                                      positional_encoding_table(5000, d).unsqueeze(1))
+            for l in range(self.cfg.n_layers):
+                rp, npfx = f"transformer_encoder.layers.{l}.", f"policy.layers.{l}."
+                for kind in ("weight", "bias"):
+                    key = rp + f"self_attn.in_proj_{kind}"
+                    full = self.passive.get("policy." + key)
+                    if full is None:
+                        full = torch.zeros((3 * d, d) if kind == "weight" else (3 * d,))
+                        if kind == "weight":
+                            torch.nn.init.xavier_uniform_(full)
+                    full = full.clone()
+                    full[2 * d:3 * d] = self.view(npfx + f"v_proj.{kind}").cpu()
+                    out[key] = full
+                    out[rp + f"self_attn.out_proj.{kind}"] = self.view(npfx + f"out_proj.{kind}").cpu().clone()
+                    for m in ("linear1", "linear2", "norm1", "norm2"):
+                        out[rp + f"{m}.{kind}"] = self.view(npfx + f"{m}.{kind}").cpu().clone()
+            for kind in ("weight", "bias"):
+                out[f"feature_norm.{kind}"] = self.view(f"policy.feature_norm.{kind}").cpu().clone()
+                for i in (0, 2, 4, 6, 8):
+                    out[f"policy_head.{i}.{kind}"] = self.view(f"policy.policy_head.{i}.{kind}").cpu().clone()
+            for k, v in self.passive.items():
+                if k.startswith("policy.value_head"):
+                    out[k[len("policy."):]] = v.clone()
+            return out
+        pre = net + "."
+        return {n[len(pre):]: self.view(n).cpu().clone() for n, _, _, _ in self.table if n.startswith(pre)}
+
+    # -- hot path
+    def act(self, obs: torch.Tensor, eps: Optional[torch.Tensor] = None, out=None):
+        """-> (action[n,A] clamped to [-1,1], mean, log_std); eps None = deterministic."""
+        n, A = obs.shape[0], self.cfg.act_dim
+        assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.cfg.obs_dim
+        if out is None:
+            out = tuple(torch.empty((n, A), dtype=torch.float32, device=self.device) for _ in range(3))
+        act, mean, ls = out
+        nat.check(self.L.tvc_sac_act(self._h, obs.data_ptr(), n, nat.ptr(eps), act.data_ptr(), mean.data_ptr(), ls.data_ptr(),
+                                     self._stream()))
+        return act, mean, ls
+
+    def update(self, s, a, r, s2, d, eps_next, eps_new, all_reduce=None, grad_scale: float = 1.0):
+        """One _update_sac.  all_reduce(tensor) is called on the critic and then on the actor gradient
+        slices between the grads and apply phases (data-parallel training); losses stay on the device."""
+        L, h, st = self.L, self._h, self._stream()
+        if all_reduce is None:
+            nat.check(L.tvc_sac_update(h, s.data_ptr(), a.data_ptr(), r.data_ptr(), s2.data_ptr(), d.data_ptr(),
+                                       eps_next.data_ptr(), eps_new.data_ptr(), self.losses.data_ptr(), st))
+            return self.losses
+        nat.check(L.tvc_sac_critic_grads(h, s.data_ptr(), a.data_ptr(), r.data_ptr(), s2.data_ptr(), d.data_ptr(),
+                                         eps_next.data_ptr(), self.losses.data_ptr(), st))
+        all_reduce(self.grads[self.n_policy:])
+        nat.check(L.tvc_sac_critic_apply(h, grad_scale, st))
+        nat.check(L.tvc_sac_actor_grads(h, s.data_ptr(), eps_new.data_ptr(), self.losses.data_ptr(), st))
+        all_reduce(self.grads[:self.n_policy])
+        nat.check(L.tvc_sac_actor_apply(h, grad_scale, st))
+        return self.losses
+
+    def q_values(self, s, a, target=False):
+        q = torch.empty((2, s.shape[0]), dtype=torch.float32, device=self.device)
+        nat.check(self.L.tvc_sac_q_values(self._h, s.data_ptr(), a.data_ptr(), s.shape[0], 1 if target else 0, q.data_ptr(),
+                                          self._stream()))
+        return q
+
+
+class ReplayBuffer:
+    """Device-resident uniform replay (capacity 1M x 96 B = 96 MB at the BASELINE shapes)."""
+
+    def __init__(self, capacity: int, obs_dim: int = 10, act_dim: int = 2, device="cuda:0", seed: int = 0):
+        self.L = nat.load()
+        self.device = torch.device(device)
+        self.capacity, self.obs_dim, self.act_dim, self.seed = capacity, obs_dim, act_dim, seed
+        self._h = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        nat.check(self.L.tvc_replay_create(capacity, obs_dim, act_dim, dev_index, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.L.tvc_replay_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self.L.tvc_replay_size(self._h))
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def insert(self, s, a, r, s2, term, trunc=None):
+        n = s.shape[0]
+        nat.check(self.L.tvc_replay_insert(self._h, s.data_ptr(), a.data_ptr(), r.data_ptr(), s2.data_ptr(), term.data_ptr(),
+                                           nat.ptr(trunc), n, self._stream()))
+
+    def store_transition(self, obs, action, reward, next_obs, done):
+        """legacy single-transition surface (tests/test_agent.py:99-108)"""
+        dev = self.device
+        f = lambda x, n: torch.as_tensor(np.asarray(x, dtype=np.float32).reshape(1, n), device=dev)
+        self.insert(f(obs, self.obs_dim), f(action, self.act_dim), torch.tensor([float(reward)], device=dev),
+                    f(next_obs, self.obs_dim), torch.tensor([1 if done else 0], dtype=torch.uint8, device=dev))
+
+    def sample(self, batch: int, counter: Optional[int] = None, out=None):
+        dev = self.device
+        if out is None:
+            out = (torch.empty((batch, self.obs_dim), device=dev), torch.empty((batch, self.act_dim), device=dev),
+                   torch.empty((batch,), device=dev), torch.empty((batch, self.obs_dim), device=dev),
+                   torch.empty((batch,), device=dev))
+        s, a, r, s2, d = out
+        nat.check(self.L.tvc_replay_sample(self._h, batch, self.seed, AUTO_COUNTER if counter is None else counter,
+                                           s.data_ptr(), a.data_ptr(), r.data_ptr(), s2.data_ptr(), d.data_ptr(),
+                                           self._stream()))
+        return out
+
+
+class MultiAlgorithmAgent:
+    """Drop-in for the reference class of the same name (agent/multi_algorithm_agent.py:419) on the SAC path.
+
+    Same constructor ``(obs_dim, action_dim, config)`` and methods ``select_algorithm``, ``get_action``,
+    ``update``, ``update_performance``, ``save_checkpoint``, ``load_checkpoint``, ``to``; attributes
+    ``performance_history``, ``algorithms``, ``device``.  PPO / TD3 / ensemble / hierarchical paths are out of
+    scope: ``select_algorithm`` answers 'sac'.  Deliberate fix: ``update`` accepts
+    the BoolTensor ``dones`` that scripts/train.py:582 builds (the reference raises on it and skips the update).
+    """
+
+    def __init__(self, obs_dim: int, action_dim: int, config: dict, device=None, seed: int = 42):
+        self.obs_dim, self.action_dim, self.config = obs_dim, action_dim, config or {}
+        self.logger = logging.getLogger(__name__)
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        native = self.config.get("tvc_native", {}) or {}
+        net = self.config.get("network", {}) or {}
+        tr = net.get("transformer", {}) or {}
+        hd = (net.get("mlp_backbone", {}) or {}).get("hidden_dims", [512, 512, 256])
+        family = int(native.get("family", 0))
+        self.batch_size = int(native.get("batch_size", 1))
+        cfg = sac_cfg(family, obs_dim=obs_dim, act_dim=action_dim, d_model=int(tr.get("d_model", 256)),
+                      n_layers=int(tr.get("num_layers", 4)), ff_dim=int(tr.get("dim_feedforward", 512)),
+                      head1=int(hd[0]), head2=int(hd[1]), batch_size=self.batch_size,
+                      max_act_rows=int(native.get("max_act_rows", 4096)), pe_rows=int(native.get("pe_rows", 1)))
+        self.sac = NativeSAC(cfg, device=self.device, seed=seed)
+        self.algorithms = {"sac": {"type": "sac", "native": self.sac}}
+        self.algorithm_weights = {"sac": 1.0}
+        self.performance_history = {alg: deque(maxlen=100) for alg in ["ppo", "sac", "td3"]}
+        self.selection_strategy = (self.config.get("algorithms", {}).get("ensemble", {}) or {}).get("selection_strategy", "dynamic")
+        self._gen = torch.Generator(device=self.device).manual_seed(seed)
+        self._current_algorithm = "sac"
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            self.logger.warning("MultiAlgorithmAgent(native) stays on %s (requested %s)", self.device, device)
+        return self
+
+    def select_algorithm(self, performance_metrics: Optional[Dict] = None):
+        self._current_algorithm = "sac"
+        return "sac"
+
+    def get_action(self, state: torch.Tensor, deterministic: bool = False, algorithm: Optional[str] = None):
+        """-> (np.ndarray[B, A], info) like agent/...:736-809 (SAC policy, clamp to [-1,1])."""
+        try:
+            state = torch.as_tensor(state, dtype=torch.float32, device=self.device)
+            if state.dim() == 1:
+                state = state.unsqueeze(0)
+            state = state.contiguous()
+            eps = None if deterministic else torch.randn((state.shape[0], self.action_dim), device=self.device, generator=self._gen)
+            act, mean, ls = self.sac.act(state, eps)
+            info = {"algorithm": "sac", "mean": mean.cpu().numpy(), "log_std": ls.cpu().numpy(), "value": None}
+            return act.cpu().numpy(), info
+        except Exception as e:  # reference convention: log and fall back to a random action (agent/...:804-809)
+            self.logger.error(f"Error in get_action: {e}")
+            return np.random.uniform(-1.0, 1.0, size=(self.action_dim,)), {"algorithm": "fallback", "error": str(e)}
+
+    def update(self, batch: Dict, algorithm: Optional[str] = None):
+        """-> dict of float losses like agent/...:868-912; never raises (returns {'error': msg})."""
+        try:
+            f = lambda k, shape: torch.as_tensor(batch[k]).to(device=self.device, dtype=torch.float32).reshape(shape).contiguous()
+            B = int(torch.as_tensor(batch["states"]).reshape(-1, self.obs_dim).shape[0])
+            if B != self.batch_size:
+                raise ValueError(f"batch of {B} rows, agent built for tvc_native.batch_size={self.batch_size}")
+            s, s2 = f("states", (B, self.obs_dim)), f("next_states", (B, self.obs_dim))
+            a, r, d = f("actions", (B, self.action_dim)), f("rewards", (B,)), f("dones", (B,))
+            e1 = torch.randn((B, self.action_dim), device=self.device, generator=self._gen)
+            e2 = torch.randn((B, self.action_dim), device=self.device, generator=self._gen)
+            losses = self.sac.update(s, a, r, s2, d, e1, e2).cpu().tolist()
+            out = {"q1_loss": losses[0], "q2_loss": losses[1], "policy_loss": losses[2]}
+            if (self.config.get("physics_informed", {}) or {}).get("enabled", False) and losses[3] > 0:
+                out["physics_loss"] = losses[3]
+            return out
+        except Exception as e:
+            self.logger.error(f"Error in agent update: {e}")
+            return {"error": str(e)}
+
+    def update_performance(self, algorithm: str, performance: float):
+        if algorithm in self.performance_history:
+            self.performance_history[algorithm].append(performance)
+            if len(self.performance_history[algorithm]) >= 10:
+                recent = np.mean(list(self.performance_history[algorithm])[-10:])
+                self.algorithm_weights[algorithm] = max(0.1, recent)
+
+    # checkpoint layout of agent/...:1098-1141 (keys: algorithms.sac.{policy_state,...}, performance_history, ...)
+    def save_checkpoint(self, path: str):
+        s = self.sac
+        n0, nc = s.n_policy, s.n_critic
+        ckpt = {
+            "algorithms": {"sac": {
+                "policy_state": s.export_reference_state("policy"),
+                "q1_state": s.export_reference_state("q1"), "q2_state": s.export_reference_state("q2"),
+                "target_q1_state": s.export_reference_state("target_q1"),
+                "target_q2_state": s.export_reference_state("target_q2"),
+                "native_adam": {"m": s.adam_m.cpu(), "v": s.adam_v.cpu()},
+                "type": "sac"}},
+            "performance_history": {k: list(v) for k, v in self.performance_history.items()},
+            "algorithm_weights": self.algorithm_weights,
+            "config": self.config,
+        }
+        torch.save(ckpt, path)
+
+    def load_checkpoint(self, path: str):
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        self.performance_history = {k: deque(v, maxlen=100) for k, v in ckpt["performance_history"].items()}
+        self.algorithm_weights = ckpt["algorithm_weights"]
+        d = ckpt["algorithms"]["sac"]
+        for net in ("policy", "q1", "q2", "target_q1", "target_q2"):
+            self.sac.load_reference_state(net, d[f"{net}_state"])
+        if "native_adam" in d:
+            self.sac.adam_m.copy_(d["native_adam"]["m"])
+            self.sac.adam_v.copy_(d["native_adam"]["v"])

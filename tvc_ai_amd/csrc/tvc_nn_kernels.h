@@ -1,0 +1,396 @@
+// Device kernels of the SAC learner (fp32, MFMA f32 16x16x4 for every GEMM-shaped contraction).
+//
+// They replace the PyTorch eager op sequences of the reference's agent/multi_algorithm_agent.py:
+//   nn.Linear (+bias, GELU / ReLU, residual)            -> gemm_kernel (fused epilogues)
+//   nn.LayerNorm forward / backward                      -> layernorm_fwd_kernel / layernorm_bwd_kernel
+//   Linear(hidden -> 2A) / Linear(hidden -> 1) heads     -> head_fwd_kernel / head_bwd_kernel (dot-reductions, no MFMA)
+//   torch.optim.Adam.step, Polyak soft update            -> adam_kernel / polyak_kernel
+// Numerics: v_mfma_f32_16x16x4_f32 is an exact-f32 k-ordered fma chain (no TF32 on gfx950), so results
+// match torch fp32 to summation-order rounding.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace tvcnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.7071067811865476f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float act_f(float x, int act) {
+    return act == ACT_GELU ? gelu_f(x) : (act == ACT_RELU ? fmaxf(x, 0.0f) : x);
+}
+__device__ __forceinline__ float act_grad(float z, int act) {
+    return act == ACT_GELU ? gelu_grad(z) : (act == ACT_RELU ? (z > 0.0f ? 1.0f : 0.0f) : 1.0f);
+}
+
+// ------------------------------------------------------------------ GEMM  C[M,N] = epi(sum_k A(m,k) * B(n,k))
+struct GemmArgs {
+    const float* A;   // A_KC: A[m*lda + k]   else A[k*lda + m]
+    const float* A2;  // optional second source for k >= K1 (concatenated input [s | a]); A_KC only
+    const float* B;   // B_KC: B[n*ldb + k]   else B[k*ldb + n]
+    float* C;         // C[m*ldc + n]
+    int M, N, K, K1;
+    long lda, lda2, ldb, ldc;
+    const float* bias;      // [N]
+    const float* rowtab;    // [rowtab_rows, N], row min(m, rows-1) added (positional-encoding table)
+    int rowtab_rows;
+    float* Zout;            // pre-activation copy (for backward), ldc
+    int act;                // applied after bias/rowtab
+    const float* Radd;      // added after act, ldc (residual / second gradient contribution)
+    const float* dactZ;     // multiply by act'(dactZ[m,n]) (dact) after Radd: dgrad epilogue
+    int dact;
+    float* colsum;          // atomic column sums of the final output (bias gradient)
+    // per-group element strides (blockIdx.z)
+    long gA, gA2, gB, gC, gBias, gZ, gR, gDZ, gCol;
+};
+
+constexpr int GBM = 64, GBN = 64, GBK = 16, GLD = GBK + 4;  // LDS rows padded to 20 floats (16-B aligned)
+
+template <bool KC>
+__device__ __forceinline__ void gemm_load_tile(const float* __restrict__ P, const float* __restrict__ P2, int K1, long ld,
+                                               long ld2, int row0, int n_rows, int k0, int K, float (&r)[4], int tid,
+                                               bool fast) {
+    // tile = 64 rows x 16 k.  KC: thread -> row tid/4, k (tid%4)*4..+3 ; !KC: thread -> k tid/16, rows (tid%16)*4..+3
+    if (KC) {
+        const int row = row0 + (tid >> 2), kk = k0 + (tid & 3) * 4;
+        if (fast) {
+            const float4 v = *reinterpret_cast<const float4*>(P + (long)row * ld + kk);
+            r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kk + j;
+                float v = 0.0f;
+                if (row < n_rows && k < K) v = (P2 != nullptr && k >= K1) ? P2[(long)row * ld2 + (k - K1)] : P[(long)row * ld + k];
+                r[j] = v;
+            }
+        }
+    } else {
+        const int k = k0 + (tid >> 4), row = row0 + (tid & 15) * 4;
+        if (fast) {
+            const float4 v = *reinterpret_cast<const float4*>(P + (long)k * ld + row);
+            r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = (k < K && row + j < n_rows) ? P[(long)k * ld + row + j] : 0.0f;
+        }
+    }
+}
+template <bool KC>
+__device__ __forceinline__ void gemm_store_tile(float (*S)[GLD], const float (&r)[4], int tid) {
+    if (KC) {
+        *reinterpret_cast<float4*>(&S[tid >> 2][(tid & 3) * 4]) = make_float4(r[0], r[1], r[2], r[3]);
+    } else {
+        const int k = tid >> 4, row = (tid & 15) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) S[row + j][k] = r[j];
+    }
+}
+
+template <bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[GBM][GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[GBN][GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    const long z = blockIdx.z;
+    const float* A = g.A + z * g.gA;
+    const float* A2 = g.A2 ? g.A2 + z * g.gA2 : nullptr;
+    const float* B = g.B + z * g.gB;
+    // fast (16-byte) global loads only when the whole tile is in range and the leading dims / bases are aligned
+    const bool a_al = ((g.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0) && A2 == nullptr;
+    const bool b_al = ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+    const bool a_rows_full = m0 + GBM <= g.M, b_rows_full = n0 + GBN <= g.N;
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float ra[4], rb[4];
+    const int nk = (g.K + GBK - 1) / GBK;
+    {
+        const bool kfull = GBK <= g.K;
+        gemm_load_tile<A_KC>(A, A2, g.K1, g.lda, g.lda2, m0, g.M, 0, g.K, ra, tid, a_al && a_rows_full && kfull);
+        gemm_load_tile<B_KC>(B, nullptr, 0, g.ldb, 0, n0, g.N, 0, g.K, rb, tid, b_al && b_rows_full && kfull);
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // previous tile's fragment reads are done
+        gemm_store_tile<A_KC>(As, ra, tid);
+        gemm_store_tile<B_KC>(Bs, rb, tid);
+        __syncthreads();
+        if (kt + 1 < nk) {  // prefetch the next tile into registers while this one is multiplied
+            const int k0 = (kt + 1) * GBK;
+            const bool kfull = k0 + GBK <= g.K;
+            gemm_load_tile<A_KC>(A, A2, g.K1, g.lda, g.lda2, m0, g.M, k0, g.K, ra, tid, a_al && a_rows_full && kfull);
+            gemm_load_tile<B_KC>(B, nullptr, 0, g.ldb, 0, n0, g.N, k0, g.K, rb, tid, b_al && b_rows_full && kfull);
+        }
+        // lane l holds k-slots 4*(l>>4)..+3 of row/col (l&15): one 16-byte LDS read feeds four MFMAs
+        float4 a4[2], b4[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a4[i] = *reinterpret_cast<const float4*>(&As[wr * 32 + i * 16 + (lane & 15)][(lane >> 4) * 4]);
+            b4[i] = *reinterpret_cast<const float4*>(&Bs[wc * 32 + i * 16 + (lane & 15)][(lane >> 4) * 4]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
+            }
+    }
+    // epilogue.  C/D map of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+    float* C = g.C + z * g.gC;
+    const float* bias = g.bias ? g.bias + z * g.gBias : nullptr;
+    float* Zout = g.Zout ? g.Zout + z * g.gZ : nullptr;
+    const float* Radd = g.Radd ? g.Radd + z * g.gR : nullptr;
+    const float* dZ = g.dactZ ? g.dactZ + z * g.gDZ : nullptr;
+    float* colsum = g.colsum ? g.colsum + z * g.gCol : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wc * 32 + j * 16 + (lane & 15);
+        const bool cok = col < g.N;
+        const float bv = (bias && cok) ? bias[col] : 0.0f;
+        float csum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wr * 32 + i * 16 + (lane >> 4) * 4 + r;
+                if (cok && row < g.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (g.rowtab) v += g.rowtab[(long)min(row, g.rowtab_rows - 1) * g.N + col];
+                    const long o = (long)row * g.ldc + col;
+                    if (Zout) Zout[o] = v;
+                    v = act_f(v, g.act);
+                    if (Radd) v += Radd[o];
+                    if (dZ) v *= act_grad(dZ[o], g.dact);
+                    C[o] = v;
+                    csum += v;
+                }
+            }
+        }
+        if (colsum) {
+            csum += __shfl_xor(csum, 16);
+            csum += __shfl_xor(csum, 32);
+            if ((lane >> 4) == 0 && cok) atomicAdd(&colsum[col], csum);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ LayerNorm (eps 1e-5, biased variance): one wave per row
+struct LnArgs {
+    const float* X; float* Y; const float* gamma; const float* beta;
+    float* mean; float* rstd;  // [M] saved for backward (may be null)
+    int M, N;                  // N in {256, 512} (multiple of 256 handled as N/64 floats per lane, <= 8)
+    long gX, gY, gP, gS;       // group strides: activations, params, stats
+};
+template <int VPL>  // values per lane = N / 64
+__global__ void __launch_bounds__(256) layernorm_fwd_kernel(LnArgs a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.M) return;
+    const long z = blockIdx.y;
+    const float* x = a.X + z * a.gX + (long)row * a.N;
+    float v[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; i += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(x + (i / 4) * 256 + lane * 4);
+        v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s += v[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)a.N;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { const float d = v[i] - mean; q += d * d; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)a.N + 1e-5f);
+    const float* gm = a.gamma + z * a.gP;
+    const float* bt = a.beta + z * a.gP;
+    float* y = a.Y + z * a.gY + (long)row * a.N;
+#pragma unroll
+    for (int i = 0; i < VPL; i += 4) {
+        const int c = (i / 4) * 256 + lane * 4;
+        const float4 gg = *reinterpret_cast<const float4*>(gm + c), bb = *reinterpret_cast<const float4*>(bt + c);
+        float4 o;
+        o.x = (v[i] - mean) * rstd * gg.x + bb.x;
+        o.y = (v[i + 1] - mean) * rstd * gg.y + bb.y;
+        o.z = (v[i + 2] - mean) * rstd * gg.z + bb.z;
+        o.w = (v[i + 3] - mean) * rstd * gg.w + bb.w;
+        *reinterpret_cast<float4*>(y + c) = o;
+    }
+    if (lane == 0 && a.mean) {
+        a.mean[z * a.gS + row] = mean;
+        a.rstd[z * a.gS + row] = rstd;
+    }
+}
+
+// backward of Y = LN(X): dX = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dY * gamma.
+// Optional fusions: dX *= act'(Zp) (the LN input was act(Zp)); column sums of the result (bias grad of the
+// producing Linear); dgamma / dbeta accumulated with float atomics (16 rows per block).
+struct LnBwdArgs {
+    const float* dY; const float* X; const float* gamma; const float* mean; const float* rstd;
+    float* dX; float* dgamma; float* dbeta;
+    const float* Zp; int dact;  // optional
+    float* colsum;              // optional [N]
+    int M, N;
+    long gA, gP, gS;            // strides: activations (dY, X, dX, Zp), params (gamma, dgamma, dbeta, colsum), stats
+};
+template <int VPL>
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(LnBwdArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long z = blockIdx.y;
+    const float* gm = a.gamma + z * a.gP;
+    float gam[VPL], dg[VPL], db[VPL], cs[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; i += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(gm + (i / 4) * 256 + lane * 4);
+        gam[i] = t.x; gam[i + 1] = t.y; gam[i + 2] = t.z; gam[i + 3] = t.w;
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { dg[i] = 0.f; db[i] = 0.f; cs[i] = 0.f; }
+    const int row_base = blockIdx.x * 16 + wave * 4;
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = row_base + rr;
+        if (row >= a.M) break;
+        const long off = z * a.gA + (long)row * a.N;
+        const float mean = a.mean[z * a.gS + row], rstd = a.rstd[z * a.gS + row];
+        float xh[VPL], gy[VPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; i += 4) {
+            const int c = (i / 4) * 256 + lane * 4;
+            const float4 xv = *reinterpret_cast<const float4*>(a.X + off + c);
+            const float4 dv = *reinterpret_cast<const float4*>(a.dY + off + c);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xh[i + j] = (xs[j] - mean) * rstd;
+                dg[i + j] += ds[j] * xh[i + j];
+                db[i + j] += ds[j];
+                gy[i + j] = ds[j] * gam[i + j];
+                s1 += gy[i + j];
+                s2 += gy[i + j] * xh[i + j];
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        const float m1 = s1 / (float)a.N, m2 = s2 / (float)a.N;
+#pragma unroll
+        for (int i = 0; i < VPL; i += 4) {
+            const int c = (i / 4) * 256 + lane * 4;
+            float o4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o4[j] = rstd * (gy[i + j] - m1 - xh[i + j] * m2);
+            if (a.Zp) {
+                const float4 zv = *reinterpret_cast<const float4*>(a.Zp + off + c);
+                o4[0] *= act_grad(zv.x, a.dact); o4[1] *= act_grad(zv.y, a.dact);
+                o4[2] *= act_grad(zv.z, a.dact); o4[3] *= act_grad(zv.w, a.dact);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cs[i + j] += o4[j];
+            *reinterpret_cast<float4*>(a.dX + off + c) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = (i / 4) * 256 + lane * 4 + (i & 3);
+        if (a.dgamma) { atomicAdd(a.dgamma + z * a.gP + c, dg[i]); atomicAdd(a.dbeta + z * a.gP + c, db[i]); }
+        if (a.colsum) atomicAdd(a.colsum + z * a.gP + c, cs[i]);
+    }
+}
+
+// ------------------------------------------------------------------ small heads: out[m, j] = X[m,:] . W[j,:] + b[j], j < NO (<= 4)
+struct HeadArgs {
+    const float* X; const float* W; const float* b; float* out;
+    int M, K, NO;
+    long gX, gW, gB, gO;
+};
+__global__ void __launch_bounds__(256) head_fwd_kernel(HeadArgs a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.M) return;
+    const long z = blockIdx.y;
+    const float* x = a.X + z * a.gX + (long)row * a.K;
+    const float* W = a.W + z * a.gW;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane * 4; k < a.K; k += 256) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + k);
+        for (int j = 0; j < a.NO; ++j) {
+            const float4 wv = *reinterpret_cast<const float4*>(W + (long)j * a.K + k);
+            acc[j] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+        }
+    }
+    for (int j = 0; j < a.NO; ++j) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o);
+    }
+    if (lane == 0)
+        for (int j = 0; j < a.NO; ++j) a.out[z * a.gO + (long)row * a.NO + j] = acc[j] + a.b[z * a.gB + j];
+}
+// backward of the head: dX[m,k] = sum_j dOut[m,j] W[j,k];  dW[j,k] += sum_m dOut[m,j] X[m,k];  db[j] += sum_m dOut[m,j]
+struct HeadBwdArgs {
+    const float* dOut; const float* X; const float* W;
+    float* dX; float* dW; float* db;  // dW/db may be null (dgrad-only pass)
+    int M, K, NO;
+    long gD, gX, gW, gB;
+};
+__global__ void __launch_bounds__(256) head_bwd_dx_kernel(HeadBwdArgs a) {
+    const long z = blockIdx.y;
+    const int row = blockIdx.x;
+    const float* dO = a.dOut + z * a.gD + (long)row * a.NO;
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < a.NO; ++j) d[j] = dO[j];
+    for (int k = threadIdx.x; k < a.K; k += blockDim.x) {
+        float v = 0.f;
+        for (int j = 0; j < a.NO; ++j) v += d[j] * a.W[z * a.gW + (long)j * a.K + k];
+        a.dX[z * a.gX + (long)row * a.K + k] = v;
+    }
+}
+__global__ void __launch_bounds__(256) head_bwd_dw_kernel(HeadBwdArgs a) {
+    // one thread per (j, k): loops over the M rows (M = batch, a few hundred)
+    const long z = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.NO * a.K) return;
+    const int j = idx / a.K, k = idx - j * a.K;
+    float s = 0.f, sb = 0.f;
+    for (int m = 0; m < a.M; ++m) {
+        const float dv = a.dOut[z * a.gD + (long)m * a.NO + j];
+        s += dv * a.X[z * a.gX + (long)m * a.K + k];
+        sb += dv;
+    }
+    a.dW[z * a.gW + idx] += s;
+    if (k == 0) a.db[z * a.gB + j] += sb;
+}
+
+// ------------------------------------------------------------------ optimiser
+// torch.optim.Adam defaults written out (agent/...:623-625): p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+// target = tau * online + (1 - tau) * target   (agent/...:1005-1010)
+__global__ void polyak_kernel(float* __restrict__ tgt, const float* __restrict__ src, long n, float tau) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        tgt[i] = tau * src[i] + (1.0f - tau) * tgt[i];
+}
+
+}  // namespace tvcnn

@@ -1,0 +1,731 @@
+// libtvc_hip.so -- SAC learner: network definitions, forward/backward executor over the kernels of
+// tvc_nn_kernels.h, the SAC loss/elementwise kernels, Adam/Polyak, and the C ABI (include/tvc_native.h).
+//
+// Replaces MultiAlgorithmAgent._create_sac_agent / get_action (policy part) / update / _update_sac /
+// PhysicsInformedLoss, agent/multi_algorithm_agent.py:587-627, 736-809, 868-912, 950-1016, 236-285.
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "tvc_common.h"
+#include "tvc_nn_kernels.h"
+
+using namespace tvcnn;
+
+namespace {
+
+// ------------------------------------------------------------------ network description
+enum { OP_LINEAR = 0, OP_LN = 1, OP_HEAD = 2 };
+struct Op {
+    int type, in_dim, out_dim, act, src, res, rowtab;
+    long w, b;  // offsets inside the net's parameter block (LINEAR/HEAD: weight[out,in], bias[out]; LN: gamma, beta)
+};
+struct TensorInfo { std::string name; long off; int rows, cols; };
+struct NetDef {
+    std::vector<Op> ops;
+    std::vector<TensorInfo> tensors;
+    long n_params = 0;
+    int in_dim = 0;
+    std::vector<int> buf_dim, res_consumer, producer, last_use;
+    int add(int type, const std::string& name, int in, int out, int act, int src, int res, int rowtab) {
+        Op o{type, in, out, act, src, res, rowtab, 0, 0};
+        o.w = n_params;
+        if (type == OP_LN) {
+            tensors.push_back({name + ".weight", n_params, out, 1}); n_params += out;
+            o.b = n_params;
+            tensors.push_back({name + ".bias", n_params, out, 1}); n_params += out;
+        } else {
+            tensors.push_back({name + ".weight", n_params, out, in}); n_params += (long)out * in;
+            o.b = n_params;
+            tensors.push_back({name + ".bias", n_params, out, 1}); n_params += out;
+        }
+        n_params = (n_params + 3) & ~3L;  // keep every tensor 16-byte aligned
+        ops.push_back(o);
+        return (int)ops.size();  // index of the output buffer
+    }
+    void finish() {
+        const int nb = (int)ops.size() + 1;
+        buf_dim.assign(nb, 0); res_consumer.assign(nb, -1); producer.assign(nb, -1); last_use.assign(nb, -1);
+        buf_dim[0] = in_dim;
+        for (int i = 0; i < (int)ops.size(); ++i) {
+            buf_dim[i + 1] = ops[i].out_dim;
+            producer[i + 1] = i;
+            last_use[ops[i].src] = i;
+            if (ops[i].res >= 0) { res_consumer[ops[i].res] = i; last_use[ops[i].res] = i; }
+        }
+        last_use[nb - 1] = (int)ops.size();
+    }
+};
+
+static NetDef build_actor(const tvc_sac_cfg& c) {
+    NetDef n;
+    n.in_dim = c.obs_dim;
+    if (c.family == 0) {
+        const int d = c.d_model;
+        int x = n.add(OP_LINEAR, "input_embedding", c.obs_dim, d, ACT_NONE, 0, -1, 1);
+        for (int l = 0; l < c.n_layers; ++l) {
+            const std::string p = "layers." + std::to_string(l) + ".";
+            int v = n.add(OP_LINEAR, p + "v_proj", d, d, ACT_NONE, x, -1, 0);
+            int a = n.add(OP_LINEAR, p + "out_proj", d, d, ACT_NONE, v, x, 0);
+            int x1 = n.add(OP_LN, p + "norm1", d, d, 0, a, -1, 0);
+            int f = n.add(OP_LINEAR, p + "linear1", d, c.ff_dim, ACT_GELU, x1, -1, 0);
+            int g = n.add(OP_LINEAR, p + "linear2", c.ff_dim, d, ACT_NONE, f, x1, 0);
+            x = n.add(OP_LN, p + "norm2", d, d, 0, g, -1, 0);
+        }
+        x = n.add(OP_LN, "feature_norm", d, d, 0, x, -1, 0);
+        x = n.add(OP_LINEAR, "policy_head.0", d, c.head1, ACT_GELU, x, -1, 0);
+        x = n.add(OP_LN, "policy_head.2", c.head1, c.head1, 0, x, -1, 0);
+        x = n.add(OP_LINEAR, "policy_head.4", c.head1, c.head2, ACT_GELU, x, -1, 0);
+        x = n.add(OP_LN, "policy_head.6", c.head2, c.head2, 0, x, -1, 0);
+        n.add(OP_HEAD, "policy_head.8", c.head2, 2 * c.act_dim, 0, x, -1, 0);
+    } else {
+        int x = n.add(OP_LINEAR, "0", c.obs_dim, c.mlp1, ACT_RELU, 0, -1, 0);
+        x = n.add(OP_LINEAR, "2", c.mlp1, c.mlp2, ACT_RELU, x, -1, 0);
+        n.add(OP_HEAD, "4", c.mlp2, 2 * c.act_dim, 0, x, -1, 0);
+    }
+    n.finish();
+    return n;
+}
+static NetDef build_critic(const tvc_sac_cfg& c) {
+    NetDef n;
+    n.in_dim = c.obs_dim + c.act_dim;
+    if (c.family == 0) {
+        int x = n.add(OP_LINEAR, "0", n.in_dim, c.critic1, ACT_GELU, 0, -1, 0);
+        x = n.add(OP_LN, "2", c.critic1, c.critic1, 0, x, -1, 0);
+        x = n.add(OP_LINEAR, "4", c.critic1, c.critic2, ACT_GELU, x, -1, 0);
+        x = n.add(OP_LN, "6", c.critic2, c.critic2, 0, x, -1, 0);
+        n.add(OP_HEAD, "8", c.critic2, 1, 0, x, -1, 0);
+    } else {
+        int x = n.add(OP_LINEAR, "0", n.in_dim, c.critic1, ACT_RELU, 0, -1, 0);
+        x = n.add(OP_LINEAR, "2", c.critic1, c.critic2, ACT_RELU, x, -1, 0);
+        n.add(OP_HEAD, "4", c.critic2, 1, 0, x, -1, 0);
+    }
+    n.finish();
+    return n;
+}
+
+static int validate(const tvc_sac_cfg* c) {
+    if (!c) return tvc::set_error(TVC_EINVAL, "cfg is NULL");
+    if (c->obs_dim < 1 || c->act_dim < 1 || c->act_dim > 2) return tvc::set_error(TVC_EINVAL, "obs_dim >= 1, act_dim in {1,2}");
+    if (c->family != 0 && c->family != 1) return tvc::set_error(TVC_EINVAL, "family must be 0 or 1");
+    auto ok_ln = [](int d) { return d == 256 || d == 512; };
+    auto ok_k = [](int d) { return d >= 4 && (d % 4) == 0; };
+    if (c->family == 0) {
+        if (!ok_ln(c->d_model) || !ok_ln(c->head1) || !ok_ln(c->head2) || !ok_ln(c->critic1) || !ok_ln(c->critic2))
+            return tvc::set_error(TVC_EINVAL, "family 0: LayerNorm widths (d_model, head1, head2, critic1, critic2) must be 256 or 512");
+        if (!ok_k(c->ff_dim) || c->n_layers < 1 || c->n_layers > 16) return tvc::set_error(TVC_EINVAL, "bad ff_dim / n_layers");
+    } else {
+        if (!ok_k(c->mlp1) || !ok_k(c->mlp2) || !ok_k(c->critic1) || !ok_k(c->critic2))
+            return tvc::set_error(TVC_EINVAL, "family 1: hidden widths must be multiples of 4");
+    }
+    if (c->batch_size < 1 || c->max_act_rows < 1) return tvc::set_error(TVC_EINVAL, "batch_size / max_act_rows must be >= 1");
+    if (c->pe_rows < 1) return tvc::set_error(TVC_EINVAL, "pe_rows must be >= 1");
+    return 0;
+}
+
+// ------------------------------------------------------------------ execution contexts
+struct Ctx {
+    int M = 0, G = 1;
+    std::vector<float*> Y, dY, Z, mean, rstd;  // per buffer index
+    std::vector<long> gY;                       // group stride (elements) per buffer
+};
+
+static void launch_gemm(bool a_kc, bool b_kc, const GemmArgs& g, int G, hipStream_t st) {
+    dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, G), block(256);
+    if (a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, st, g);
+    else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, st, g);
+    else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, st, g);
+}
+
+// forward of one net (G parameter groups batched through blockIdx.z).  X: [G?][M,in]; gX = 0 shares one input.
+static void net_forward(const NetDef& nd, const float* P, long gP, const float* X, long gX, int M, int G, Ctx& c, bool save,
+                        const float* pe, int pe_rows, hipStream_t st) {
+    for (int i = 0; i < (int)nd.ops.size(); ++i) {
+        const Op& o = nd.ops[i];
+        const int out = i + 1;
+        const float* in = o.src == 0 ? X : c.Y[o.src];
+        const long gin = o.src == 0 ? gX : c.gY[o.src];
+        if (o.type == OP_LINEAR) {
+            GemmArgs g{};
+            g.A = in; g.B = P + o.w; g.C = c.Y[out];
+            g.M = M; g.N = o.out_dim; g.K = o.in_dim; g.K1 = o.in_dim;
+            g.lda = o.in_dim; g.ldb = o.in_dim; g.ldc = o.out_dim;
+            g.bias = P + o.b;
+            if (o.rowtab && pe) { g.rowtab = pe; g.rowtab_rows = pe_rows; }
+            g.Zout = (save && o.act != ACT_NONE) ? c.Z[out] : nullptr;
+            g.act = o.act;
+            g.Radd = o.res >= 0 ? (o.res == 0 ? X : c.Y[o.res]) : nullptr;
+            g.gA = gin; g.gB = gP; g.gC = c.gY[out]; g.gBias = gP; g.gZ = c.gY[out];
+            g.gR = o.res >= 0 ? (o.res == 0 ? gX : c.gY[o.res]) : 0;
+            launch_gemm(true, true, g, G, st);
+        } else if (o.type == OP_LN) {
+            LnArgs a{};
+            a.X = in; a.Y = c.Y[out]; a.gamma = P + o.w; a.beta = P + o.b;
+            a.mean = save ? c.mean[out] : nullptr; a.rstd = save ? c.rstd[out] : nullptr;
+            a.M = M; a.N = o.out_dim; a.gX = gin; a.gY = c.gY[out]; a.gP = gP; a.gS = M;
+            dim3 grid((M + 3) / 4, G), block(256);
+            if (o.out_dim == 256) hipLaunchKernelGGL((layernorm_fwd_kernel<4>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((layernorm_fwd_kernel<8>), grid, block, 0, st, a);
+        } else {
+            HeadArgs a{};
+            a.X = in; a.W = P + o.w; a.b = P + o.b; a.out = c.Y[out];
+            a.M = M; a.K = o.in_dim; a.NO = o.out_dim; a.gX = gin; a.gW = gP; a.gB = gP; a.gO = c.gY[out];
+            hipLaunchKernelGGL(head_fwd_kernel, dim3((M + 3) / 4, G), dim3(256), 0, st, a);
+        }
+    }
+}
+
+__global__ void head_bwd_dx_act_kernel(HeadBwdArgs a, const float* Zp, long gZ, int dact, float* colsum, long gCol) {
+    // as head_bwd_dx_kernel, then dX *= act'(Zp) and column sums (the producer of X is an activated Linear)
+    const long z = blockIdx.y;
+    const int row = blockIdx.x;
+    const float* dO = a.dOut + z * a.gD + (long)row * a.NO;
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < a.NO; ++j) d[j] = dO[j];
+    for (int k = threadIdx.x; k < a.K; k += blockDim.x) {
+        float v = 0.f;
+        for (int j = 0; j < a.NO; ++j) v += d[j] * a.W[z * a.gW + (long)j * a.K + k];
+        v *= act_grad(Zp[z * gZ + (long)row * a.K + k], dact);
+        a.dX[z * a.gX + (long)row * a.K + k] = v;
+        if (colsum) atomicAdd(colsum + z * gCol + k, v);
+    }
+}
+
+// backward of one net.  c.dY[last] must hold the gradient w.r.t. the head output.  Gr == nullptr: data
+// gradients only (the critics inside the actor step).  Returns the input gradient in c.dY[0] when wanted.
+static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, long gG, const float* X, long gX, int M, int G,
+                         Ctx& c, bool want_input_grad, hipStream_t st) {
+    for (int i = (int)nd.ops.size() - 1; i >= 0; --i) {
+        const Op& o = nd.ops[i];
+        const int out = i + 1;
+        const float* in = o.src == 0 ? X : c.Y[o.src];
+        const long gin = o.src == 0 ? gX : c.gY[o.src];
+        const int prod = nd.producer[o.src];
+        const Op* po = prod >= 0 ? &nd.ops[prod] : nullptr;
+        const bool prod_lin = po && po->type == OP_LINEAR;
+        const bool prod_act = prod_lin && po->act != ACT_NONE;
+        float* prod_bias_grad = (Gr && prod_lin) ? Gr + po->b : nullptr;
+        if (o.type == OP_HEAD) {
+            HeadBwdArgs a{};
+            a.dOut = c.dY[out]; a.X = in; a.W = P + o.w; a.dX = c.dY[o.src];
+            a.dW = Gr ? Gr + o.w : nullptr; a.db = Gr ? Gr + o.b : nullptr;
+            a.M = M; a.K = o.in_dim; a.NO = o.out_dim;
+            a.gD = c.gY[out]; a.gX = gin; a.gW = gP; a.gB = gP;
+            HeadBwdArgs ad = a;  // dX uses the activation-gradient stride of the source buffer
+            ad.gX = c.gY[o.src];
+            if (prod_act)
+                hipLaunchKernelGGL(head_bwd_dx_act_kernel, dim3(M, G), dim3(256), 0, st, ad, c.Z[o.src], c.gY[o.src], po->act,
+                                   prod_bias_grad, gG);
+            else
+                hipLaunchKernelGGL(head_bwd_dx_kernel, dim3(M, G), dim3(256), 0, st, ad);
+            if (Gr) {
+                HeadBwdArgs aw = a;
+                aw.gW = gG; aw.gB = gG;
+                hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((o.out_dim * o.in_dim + 255) / 256, G), dim3(256), 0, st, aw);
+            }
+        } else if (o.type == OP_LN) {
+            LnBwdArgs a{};
+            a.dY = c.dY[out]; a.X = in; a.gamma = P + o.w; a.mean = c.mean[out]; a.rstd = c.rstd[out];
+            a.dX = c.dY[o.src];
+            a.dgamma = Gr ? Gr + o.w : nullptr; a.dbeta = Gr ? Gr + o.b : nullptr;
+            a.Zp = prod_act ? c.Z[o.src] : nullptr; a.dact = prod_act ? po->act : 0;
+            a.colsum = prod_bias_grad;
+            a.M = M; a.N = o.out_dim;
+            a.gA = c.gY[out]; a.gP = Gr ? gG : gP; a.gS = M;
+            // gamma is read with the PARAMETER stride, dgamma written with the GRADIENT stride: both nets use the
+            // same block layout, so the strides coincide whenever Gr != nullptr (gG == gP is asserted at create)
+            dim3 grid((M + 15) / 16, G), block(256);
+            if (o.out_dim == 256) hipLaunchKernelGGL((layernorm_bwd_kernel<4>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((layernorm_bwd_kernel<8>), grid, block, 0, st, a);
+        } else {  // LINEAR: c.dY[out] already holds dZ (act' and bias column sums were fused by its writer)
+            const float* dZ = c.dY[out];
+            if (Gr) {  // dW[out,in] = dZ^T X
+                GemmArgs g{};
+                g.A = dZ; g.B = in; g.C = Gr + o.w;
+                g.M = o.out_dim; g.N = o.in_dim; g.K = M; g.K1 = M;
+                g.lda = o.out_dim; g.ldb = o.in_dim; g.ldc = o.in_dim;
+                g.gA = c.gY[out]; g.gB = gin; g.gC = gG;
+                launch_gemm(false, false, g, G, st);
+            }
+            if (o.src > 0 || want_input_grad) {  // dX[M,in] = dZ W (+ residual-branch gradient) (* act' of the producer)
+                GemmArgs g{};
+                g.A = dZ; g.B = P + o.w; g.C = c.dY[o.src];
+                g.M = M; g.N = o.in_dim; g.K = o.out_dim; g.K1 = o.out_dim;
+                g.lda = o.out_dim; g.ldb = o.in_dim; g.ldc = o.in_dim;
+                g.gA = c.gY[out]; g.gB = gP; g.gC = c.gY[o.src];
+                const int rc = nd.res_consumer[o.src];
+                if (rc >= 0 && rc != i) { g.Radd = c.dY[rc + 1]; g.gR = c.gY[rc + 1]; }
+                if (prod_act) { g.dactZ = c.Z[o.src]; g.dact = po->act; g.gDZ = c.gY[o.src]; }
+                if (prod_bias_grad) { g.colsum = prod_bias_grad; g.gCol = gG; }
+                launch_gemm(true, false, g, G, st);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ SAC elementwise kernels
+__global__ void concat_kernel(const float* __restrict__ s, const float* __restrict__ a, float* __restrict__ x, int M, int no,
+                              int na) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * (no + na)) return;
+    const int m = i / (no + na), k = i - m * (no + na);
+    x[i] = k < no ? s[(long)m * no + k] : a[(long)m * na + (k - no)];
+}
+
+// head output [M,2A] -> mean, clamped log_std, action = mean + exp(log_std) * eps  (agent/...:224-225, 780-782, 964-966)
+__global__ void sample_action_kernel(const float* __restrict__ head, const float* __restrict__ eps, float* __restrict__ act,
+                                     float* __restrict__ mean_out, float* __restrict__ ls_out, int M, int A, int clamp_act) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * A) return;
+    const int m = i / A, j = i - m * A;
+    const float mu = head[(long)m * 2 * A + j];
+    const float ls = fminf(fmaxf(head[(long)m * 2 * A + A + j], -20.0f), 2.0f);
+    float a = eps ? mu + expf(ls) * eps[i] : mu;
+    if (clamp_act) a = fminf(fmaxf(a, -1.0f), 1.0f);
+    act[i] = a;
+    if (mean_out) mean_out[i] = mu;
+    if (ls_out) ls_out[i] = ls;
+}
+
+// y = r + gamma (1 - d) min(tq1, tq2)   (agent/...:968-971)
+__global__ void td_target_kernel(const float* __restrict__ tq, const float* __restrict__ r, const float* __restrict__ d,
+                                 float* __restrict__ y, int M, float gamma) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    y[m] = r[m] + gamma * (1.0f - d[m]) * fminf(tq[m], tq[M + m]);
+}
+
+__device__ __forceinline__ float block_sum(float v) {
+    __shared__ float part[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return part[0] + part[1] + part[2] + part[3];
+}
+
+// q [2,M], y [M] -> dq = 2 (q - y) / M, losses[g] += mean((q - y)^2)   (agent/...:976-977)
+__global__ void __launch_bounds__(256) q_loss_kernel(const float* __restrict__ q, const float* __restrict__ y,
+                                                     float* __restrict__ dq, float* __restrict__ losses, int M) {
+    const int g = blockIdx.y;
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    float e = 0.f;
+    if (m < M) {
+        const float diff = q[(long)g * M + m] - y[m];
+        dq[(long)g * M + m] = 2.0f * diff / (float)M;
+        e = diff * diff / (float)M;
+    }
+    const float s = block_sum(e);
+    if (threadIdx.x == 0) atomicAdd(&losses[g], s);
+}
+
+// policy loss and its gradient w.r.t. the two critic outputs (agent/...:994-998)
+__global__ void __launch_bounds__(256) actor_loss_kernel(const float* __restrict__ qn, const float* __restrict__ ls,
+                                                         const float* __restrict__ eps, float* __restrict__ dqn,
+                                                         float* __restrict__ losses, int M, int A, float alpha) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    float e = 0.f;
+    if (m < M) {
+        float logp = 0.f;
+        for (int j = 0; j < A; ++j) {
+            const float ep = eps[(long)m * A + j];
+            logp += -0.5f * ep * ep - ls[(long)m * A + j] - 0.9189385332046727f;  // log sqrt(2 pi)
+        }
+        const float q1 = qn[m], q2 = qn[M + m];
+        const bool first = q1 <= q2;
+        e = -(fminf(q1, q2) - alpha * logp) / (float)M;
+        dqn[m] = first ? -1.0f / (float)M : 0.0f;
+        dqn[M + m] = first ? 0.0f : -1.0f / (float)M;
+    }
+    const float s = block_sum(e);
+    if (threadIdx.x == 0) atomicAdd(&losses[2], s);
+}
+
+// gradient w.r.t. the policy head output [M,2A] from d(a_new) (two critics' input gradients) and the entropy term
+__global__ void actor_head_grad_kernel(const float* __restrict__ dxin, long g_stride, int in_dim, int obs_dim,
+                                       const float* __restrict__ head, const float* __restrict__ eps,
+                                       float* __restrict__ dhead, int M, int A, float alpha) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * A) return;
+    const int m = i / A, j = i - m * A;
+    const float da = dxin[(long)m * in_dim + obs_dim + j] + dxin[g_stride + (long)m * in_dim + obs_dim + j];
+    const float raw = head[(long)m * 2 * A + A + j];
+    const float ls = fminf(fmaxf(raw, -20.0f), 2.0f);
+    const bool pass = raw >= -20.0f && raw <= 2.0f;  // torch.clamp passes the gradient on [min, max]
+    dhead[(long)m * 2 * A + j] = da;
+    dhead[(long)m * 2 * A + A + j] = pass ? (da * expf(ls) * eps[i] - alpha / (float)M) : 0.0f;
+}
+
+// PhysicsInformedLoss.forward (agent/...:236-285), reported only
+__global__ void __launch_bounds__(256) physics_loss_kernel(const float* __restrict__ s, const float* __restrict__ a,
+                                                           const float* __restrict__ s2, float* __restrict__ losses, int M,
+                                                           int no, int na, float weight) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    float e = 0.f;
+    if (m < M && no >= 7) {
+        const float* x = s + (long)m * no;
+        const float* x2 = s2 + (long)m * no;
+        float an2 = 0.f;
+        for (int j = 0; j < na; ++j) an2 += a[(long)m * na + j] * a[(long)m * na + j];
+        const float ctrl = sqrtf(an2) * 0.1f;
+        float mom = 0.f, ke = 0.f, ke2 = 0.f;
+        for (int j = 4; j < 7; ++j) {
+            const float d = x2[j] - (x[j] + ctrl);
+            mom += d * d;
+            ke += x[j] * x[j];
+            ke2 += x2[j] * x2[j];
+        }
+        const float de = 0.5f * ke2 - (0.5f * ke + 0.5f * an2 * 0.01f);
+        const float qn = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]) - 1.0f;
+        const float qn2 = sqrtf(x2[0] * x2[0] + x2[1] * x2[1] + x2[2] * x2[2] + x2[3] * x2[3]) - 1.0f;
+        e = weight * (mom / (3.0f * M) + de * de / (float)M + (qn * qn + qn2 * qn2) / (float)M);
+    }
+    const float sum = block_sum(e);
+    if (threadIdx.x == 0) atomicAdd(&losses[3], sum);
+}
+
+// Adam bias corrections from a device-resident step counter (keeps the update hipGraph-replayable)
+__global__ void adam_tick_kernel(int* step, float* bc, float b1, float b2) {
+    const int t = ++(*step);
+    bc[0] = (float)(1.0 - pow((double)b1, (double)t));
+    bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                long n, float lr, float b1, float b2, float eps, const float* __restrict__ bc, float gscale) {
+    const float bc1 = bc[0], bc2s = bc[1];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2s + eps);
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ handle
+struct tvc_sac {
+    tvc_sac_cfg cfg;
+    int device;
+    NetDef actor, critic;
+    long n_actor, n_critic;
+    float *params, *grads, *adam_m, *adam_v;  // caller-owned
+    void* slab = nullptr;                      // library-owned workspace
+    Ctx actx, cctx, ictx;                      // actor (train), critics (train, G=2), actor (inference, slot-aliased)
+    float *pe = nullptr, *xcat = nullptr, *a_tmp = nullptr, *y = nullptr, *dq = nullptr, *ls_tmp = nullptr, *mean_tmp = nullptr;
+    int* step = nullptr;   // [2]: critics, actor
+    float* bc = nullptr;   // [4]
+    float* P_actor() { return params; }
+    float* P_q() { return params + n_actor; }
+    float* P_tq() { return params + n_actor + 2 * n_critic; }
+    float* G_actor() { return grads; }
+    float* G_q() { return grads + n_actor; }
+};
+
+static long ctx_bytes(const NetDef& nd, int M, int G, bool train) {
+    long f = 0;
+    for (size_t b = 1; b < nd.buf_dim.size(); ++b) {
+        f += (long)G * M * nd.buf_dim[b] * (train ? 3 : 0);  // Y, dY, Z
+        f += train ? 2L * G * M : 0;                         // mean, rstd
+    }
+    f += (long)G * M * nd.buf_dim[0];  // dY[0]
+    return f * 4;
+}
+static char* carve(char*& p, long bytes) {
+    char* r = p;
+    p += (bytes + 255) & ~255L;
+    return r;
+}
+static void ctx_alloc_train(Ctx& c, const NetDef& nd, int M, int G, char*& p) {
+    const size_t nb = nd.buf_dim.size();
+    c.M = M; c.G = G;
+    c.Y.assign(nb, nullptr); c.dY.assign(nb, nullptr); c.Z.assign(nb, nullptr);
+    c.mean.assign(nb, nullptr); c.rstd.assign(nb, nullptr); c.gY.assign(nb, 0);
+    for (size_t b = 0; b < nb; ++b) {
+        const long n = (long)M * nd.buf_dim[b];
+        c.gY[b] = n;
+        c.dY[b] = (float*)carve(p, n * G * 4);
+        if (b == 0) continue;
+        c.Y[b] = (float*)carve(p, n * G * 4);
+        c.Z[b] = (float*)carve(p, n * G * 4);
+        c.mean[b] = (float*)carve(p, (long)M * G * 4);
+        c.rstd[b] = (float*)carve(p, (long)M * G * 4);
+    }
+}
+// inference: activations rotate through a few slots (a buffer's slot is reused once its last consumer ran)
+static int ctx_alloc_infer(Ctx& c, const NetDef& nd, int M, char*& p, int max_slots = 6) {
+    const size_t nb = nd.buf_dim.size();
+    c.M = M; c.G = 1;
+    c.Y.assign(nb, nullptr); c.dY.assign(nb, nullptr); c.Z.assign(nb, nullptr);
+    c.mean.assign(nb, nullptr); c.rstd.assign(nb, nullptr); c.gY.assign(nb, 0);
+    int maxd = 0;
+    for (size_t b = 1; b < nb; ++b) maxd = std::max(maxd, nd.buf_dim[b]);
+    std::vector<float*> slot(max_slots);
+    std::vector<int> free_at(max_slots, -1);  // op index after which the slot is free
+    for (int s = 0; s < max_slots; ++s) slot[s] = (float*)carve(p, (long)M * maxd * 4);
+    for (size_t b = 1; b < nb; ++b) {
+        const int prod = (int)b - 1;
+        int pick = -1;
+        for (int s = 0; s < max_slots; ++s)
+            if (free_at[s] < prod) { pick = s; break; }  // its last reader ran before this op
+        if (pick < 0) return -1;
+        c.Y[b] = slot[pick];
+        c.gY[b] = (long)M * nd.buf_dim[b];
+        free_at[pick] = nd.last_use[b];
+    }
+    return 0;
+}
+
+extern "C" {
+
+void tvc_sac_default_cfg(tvc_sac_cfg* c, int32_t family) {
+    if (!c) return;
+    memset(c, 0, sizeof(*c));
+    c->obs_dim = 10; c->act_dim = 2; c->family = family;
+    c->d_model = 256; c->n_layers = 4; c->ff_dim = 512; c->head1 = 512; c->head2 = 512;  // agent/...:451-468
+    c->mlp1 = 256; c->mlp2 = 256;
+    c->critic1 = family == 0 ? 512 : 256; c->critic2 = 256;                              // agent/...:593-603
+    c->batch_size = 256; c->max_act_rows = 65536; c->pe_rows = 1;
+    c->gamma = 0.99f; c->alpha = 0.2f; c->tau = 0.005f; c->lr = 3e-4f;                   // agent/...:971,998,1005,623
+    c->adam_b1 = 0.9f; c->adam_b2 = 0.999f; c->adam_eps = 1e-8f;
+}
+
+int64_t tvc_sac_param_count(const tvc_sac_cfg* c) {
+    if (validate(c)) return -1;
+    return build_actor(*c).n_params + 4 * build_critic(*c).n_params;
+}
+int64_t tvc_sac_trainable_count(const tvc_sac_cfg* c) {
+    if (validate(c)) return -1;
+    return build_actor(*c).n_params + 2 * build_critic(*c).n_params;
+}
+int32_t tvc_sac_num_tensors(const tvc_sac_cfg* c) {
+    if (validate(c)) return -1;
+    return (int32_t)(build_actor(*c).tensors.size() + 4 * build_critic(*c).tensors.size());
+}
+int tvc_sac_tensor_info(const tvc_sac_cfg* c, int32_t idx, char* name, int32_t cap, int64_t* offset, int32_t* rows, int32_t* cols) {
+    if (int e = validate(c)) return e;
+    NetDef a = build_actor(*c), q = build_critic(*c);
+    const char* prefixes[5] = {"policy.", "q1.", "q2.", "target_q1.", "target_q2."};
+    long base = 0;
+    int i = idx;
+    for (int net = 0; net < 5; ++net) {
+        const NetDef& nd = net == 0 ? a : q;
+        if (i < (int)nd.tensors.size()) {
+            const TensorInfo& t = nd.tensors[i];
+            if (name && cap > 0) snprintf(name, cap, "%s%s", prefixes[net], t.name.c_str());
+            if (offset) *offset = base + t.off;
+            if (rows) *rows = t.rows;
+            if (cols) *cols = t.cols;
+            return 0;
+        }
+        i -= (int)nd.tensors.size();
+        base += nd.n_params;
+    }
+    return tvc::set_error(TVC_EINVAL, "tensor index %d out of range", idx);
+}
+
+int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float* grads, float* adam_m, float* adam_v,
+                   const float* pe_host, tvc_sac** out) {
+    if (!out) return tvc::set_error(TVC_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (int e = validate(cfg)) return e;
+    if (!params || !grads || !adam_m || !adam_v) return tvc::set_error(TVC_EINVAL, "params/grads/adam buffers must be non-NULL");
+    if ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads)) & 15)
+        return tvc::set_error(TVC_EINVAL, "params/grads must be 16-byte aligned");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return tvc::set_error(TVC_ENODEV, "no HIP device visible: libtvc_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return tvc::set_error(TVC_EINVAL, "device %d out of range", device);
+    TVC_HIP_CHECK(hipSetDevice(device));
+    tvc_sac* h = new (std::nothrow) tvc_sac();
+    if (!h) return tvc::set_error(TVC_ENOMEM, "host allocation failed");
+    h->cfg = *cfg; h->device = device;
+    h->actor = build_actor(*cfg); h->critic = build_critic(*cfg);
+    h->n_actor = h->actor.n_params; h->n_critic = h->critic.n_params;
+    h->params = params; h->grads = grads; h->adam_m = adam_m; h->adam_v = adam_v;
+    const int B = cfg->batch_size, A = cfg->act_dim, NA = cfg->max_act_rows;
+    int maxd = 0;
+    for (size_t b = 1; b < h->actor.buf_dim.size(); ++b) maxd = std::max(maxd, h->actor.buf_dim[b]);
+    long bytes = ctx_bytes(h->actor, B, 1, true) + ctx_bytes(h->critic, B, 2, true) + 6L * NA * maxd * 4;
+    bytes += (long)cfg->pe_rows * cfg->d_model * 4 + (long)B * (cfg->obs_dim + A) * 4 * 2 + (long)B * 64 + (1 << 16);
+    bytes += 256L * (4 * (h->actor.buf_dim.size() + h->critic.buf_dim.size()) * 3 + 64);
+    hipError_t he = hipMalloc(&h->slab, bytes);
+    if (he != hipSuccess) {
+        delete h;
+        return tvc::set_error(TVC_ENOMEM, "hipMalloc(%ld bytes) failed: %s", bytes, hipGetErrorString(he));
+    }
+    (void)hipMemset(h->slab, 0, bytes);
+    char* p = (char*)h->slab;
+    ctx_alloc_train(h->actx, h->actor, B, 1, p);
+    ctx_alloc_train(h->cctx, h->critic, B, 2, p);
+    if (ctx_alloc_infer(h->ictx, h->actor, NA, p) != 0) {
+        (void)hipFree(h->slab);
+        delete h;
+        return tvc::set_error(TVC_EINVAL, "inference slot allocation failed");
+    }
+    h->pe = (float*)carve(p, (long)cfg->pe_rows * cfg->d_model * 4);
+    h->xcat = (float*)carve(p, (long)B * (cfg->obs_dim + A) * 4);
+    h->a_tmp = (float*)carve(p, (long)B * A * 4);
+    h->ls_tmp = (float*)carve(p, (long)B * A * 4);
+    h->mean_tmp = (float*)carve(p, (long)B * A * 4);
+    h->y = (float*)carve(p, (long)B * 4);
+    h->dq = (float*)carve(p, (long)B * 2 * 4);
+    h->step = (int*)carve(p, 16);
+    h->bc = (float*)carve(p, 16);
+    if ((long)(p - (char*)h->slab) > bytes) {
+        (void)hipFree(h->slab);
+        delete h;
+        return tvc::set_error(TVC_ENOMEM, "internal: workspace under-sized");
+    }
+    if (cfg->family == 0) {
+        if (!pe_host) {
+            (void)hipFree(h->slab);
+            delete h;
+            return tvc::set_error(TVC_EINVAL, "family 0 needs the positional-encoding table");
+        }
+        he = hipMemcpy(h->pe, pe_host, (long)cfg->pe_rows * cfg->d_model * 4, hipMemcpyHostToDevice);
+        if (he != hipSuccess) {
+            (void)hipFree(h->slab);
+            delete h;
+            return tvc::set_error(TVC_EHIP, "hipMemcpy(pe) failed: %s", hipGetErrorString(he));
+        }
+    }
+    *out = h;
+    return 0;
+}
+
+void tvc_sac_destroy(tvc_sac* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->slab);
+    delete h;
+}
+
+int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float* act, float* mean, float* logstd, void* stream) {
+    if (!h || !obs || !act) return tvc::set_error(TVC_EINVAL, "null argument");
+    if (n < 1 || n > h->cfg.max_act_rows) return tvc::set_error(TVC_EINVAL, "n=%d outside [1, max_act_rows=%d]", n, h->cfg.max_act_rows);
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int A = h->cfg.act_dim;
+    // activation group strides depend on the row count actually used
+    for (size_t b = 1; b < h->ictx.gY.size(); ++b) h->ictx.gY[b] = (long)n * h->actor.buf_dim[b];
+    net_forward(h->actor, h->P_actor(), 0, obs, 0, n, 1, h->ictx, false, h->cfg.family == 0 ? h->pe : nullptr, h->cfg.pe_rows, st);
+    const float* head = h->ictx.Y.back();
+    hipLaunchKernelGGL(sample_action_kernel, dim3((n * A + 255) / 256), dim3(256), 0, st, head, eps, act, mean, logstd, n, A, 1);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static int check_batch_ptrs(const void* a, const void* b, const void* c) {
+    if (!a || !b || !c) return tvc::set_error(TVC_EINVAL, "null batch pointer");
+    return 0;
+}
+
+int tvc_sac_critic_grads(tvc_sac* h, const float* s, const float* a, const float* r, const float* s2, const float* d,
+                         const float* eps_next, float* losses, void* stream) {
+    if (!h || !losses) return tvc::set_error(TVC_EINVAL, "null argument");
+    if (check_batch_ptrs(s, a, r) || check_batch_ptrs(s2, d, eps_next)) return TVC_EINVAL;
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const tvc_sac_cfg& c = h->cfg;
+    const int B = c.batch_size, A = c.act_dim, no = c.obs_dim, nin = no + A;
+    const float* pe = c.family == 0 ? h->pe : nullptr;
+    TVC_HIP_CHECK(hipMemsetAsync(losses, 0, 4 * sizeof(float), st));
+    hipLaunchKernelGGL(physics_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, st, s, a, s2, losses, B, no, A, 0.1f);
+    // target: a' ~ pi(s'), y = r + gamma (1-d) min(tq1, tq2)(s', a')
+    net_forward(h->actor, h->P_actor(), 0, s2, 0, B, 1, h->actx, false, pe, c.pe_rows, st);
+    hipLaunchKernelGGL(sample_action_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, h->actx.Y.back(), eps_next, h->a_tmp,
+                       (float*)nullptr, (float*)nullptr, B, A, 0);
+    hipLaunchKernelGGL(concat_kernel, dim3((B * nin + 255) / 256), dim3(256), 0, st, s2, h->a_tmp, h->xcat, B, no, A);
+    net_forward(h->critic, h->P_tq(), h->n_critic, h->xcat, 0, B, 2, h->cctx, false, nullptr, 0, st);
+    hipLaunchKernelGGL(td_target_kernel, dim3((B + 255) / 256), dim3(256), 0, st, h->cctx.Y.back(), r, d, h->y, B, c.gamma);
+    // online critics on (s, a): forward (saved), loss, backward
+    hipLaunchKernelGGL(concat_kernel, dim3((B * nin + 255) / 256), dim3(256), 0, st, s, a, h->xcat, B, no, A);
+    net_forward(h->critic, h->P_q(), h->n_critic, h->xcat, 0, B, 2, h->cctx, true, nullptr, 0, st);
+    hipLaunchKernelGGL(q_loss_kernel, dim3((B + 255) / 256, 2), dim3(256), 0, st, h->cctx.Y.back(), h->y, h->cctx.dY.back(),
+                       losses, B);
+    TVC_HIP_CHECK(hipMemsetAsync(h->G_q(), 0, 2 * h->n_critic * sizeof(float), st));
+    net_backward(h->critic, h->P_q(), h->n_critic, h->G_q(), h->n_critic, h->xcat, 0, B, 2, h->cctx, false, st);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+static void adam_apply(tvc_sac* h, float* p, float* g, long off, long n, int which, float gscale, hipStream_t st) {
+    const tvc_sac_cfg& c = h->cfg;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, h->step + which, h->bc + 2 * which, c.adam_b1, c.adam_b2);
+    const int blocks = (int)std::min<long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, st, p, g, h->adam_m + off, h->adam_v + off, n, c.lr, c.adam_b1,
+                       c.adam_b2, c.adam_eps, h->bc + 2 * which, gscale);
+}
+
+int tvc_sac_critic_apply(tvc_sac* h, float grad_scale, void* stream) {
+    if (!h) return tvc::set_error(TVC_EINVAL, "null argument");
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    adam_apply(h, h->P_q(), h->G_q(), h->n_actor, 2 * h->n_critic, 0, grad_scale, (hipStream_t)stream);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int tvc_sac_actor_grads(tvc_sac* h, const float* s, const float* eps_new, float* losses, void* stream) {
+    if (!h || !s || !eps_new || !losses) return tvc::set_error(TVC_EINVAL, "null argument");
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const tvc_sac_cfg& c = h->cfg;
+    const int B = c.batch_size, A = c.act_dim, no = c.obs_dim, nin = no + A;
+    const float* pe = c.family == 0 ? h->pe : nullptr;
+    net_forward(h->actor, h->P_actor(), 0, s, 0, B, 1, h->actx, true, pe, c.pe_rows, st);
+    const float* head = h->actx.Y.back();
+    hipLaunchKernelGGL(sample_action_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, head, eps_new, h->a_tmp, h->mean_tmp,
+                       h->ls_tmp, B, A, 0);
+    hipLaunchKernelGGL(concat_kernel, dim3((B * nin + 255) / 256), dim3(256), 0, st, s, h->a_tmp, h->xcat, B, no, A);
+    net_forward(h->critic, h->P_q(), h->n_critic, h->xcat, 0, B, 2, h->cctx, true, nullptr, 0, st);
+    hipLaunchKernelGGL(actor_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, st, h->cctx.Y.back(), h->ls_tmp, eps_new,
+                       h->cctx.dY.back(), losses, B, A, c.alpha);
+    // data gradients only through the critics (the reference also fills q.grad here, then discards it)
+    net_backward(h->critic, h->P_q(), h->n_critic, nullptr, 0, h->xcat, 0, B, 2, h->cctx, true, st);
+    hipLaunchKernelGGL(actor_head_grad_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, h->cctx.dY[0], h->cctx.gY[0], nin, no,
+                       head, eps_new, h->actx.dY.back(), B, A, c.alpha);
+    TVC_HIP_CHECK(hipMemsetAsync(h->G_actor(), 0, h->n_actor * sizeof(float), st));
+    net_backward(h->actor, h->P_actor(), 0, h->G_actor(), 0, s, 0, B, 1, h->actx, false, st);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int tvc_sac_actor_apply(tvc_sac* h, float grad_scale, void* stream) {
+    if (!h) return tvc::set_error(TVC_EINVAL, "null argument");
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    adam_apply(h, h->P_actor(), h->G_actor(), 0, h->n_actor, 1, grad_scale, st);
+    const long n = 2 * h->n_critic;
+    hipLaunchKernelGGL(polyak_kernel, dim3((int)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, st, h->P_tq(), h->P_q(), n,
+                       h->cfg.tau);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int tvc_sac_update(tvc_sac* h, const float* s, const float* a, const float* r, const float* s2, const float* d,
+                   const float* eps_next, const float* eps_new, float* losses, void* stream) {
+    if (int e = tvc_sac_critic_grads(h, s, a, r, s2, d, eps_next, losses, stream)) return e;
+    if (int e = tvc_sac_critic_apply(h, 1.0f, stream)) return e;
+    if (int e = tvc_sac_actor_grads(h, s, eps_new, losses, stream)) return e;
+    return tvc_sac_actor_apply(h, 1.0f, stream);
+}
+
+int tvc_sac_q_values(tvc_sac* h, const float* s, const float* a, int32_t n, int32_t use_target, float* q, void* stream) {
+    if (!h || !s || !a || !q) return tvc::set_error(TVC_EINVAL, "null argument");
+    if (n != h->cfg.batch_size) return tvc::set_error(TVC_EINVAL, "tvc_sac_q_values needs n == batch_size (%d)", h->cfg.batch_size);
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int A = h->cfg.act_dim, no = h->cfg.obs_dim;
+    hipLaunchKernelGGL(concat_kernel, dim3((n * (no + A) + 255) / 256), dim3(256), 0, st, s, a, h->xcat, n, no, A);
+    net_forward(h->critic, use_target ? h->P_tq() : h->P_q(), h->n_critic, h->xcat, 0, n, 2, h->cctx, false, nullptr, 0, st);
+    TVC_HIP_CHECK(hipMemcpyAsync(q, h->cctx.Y.back(), 2L * n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+}  // extern "C"
