@@ -41,6 +41,7 @@ def parse():
                     help="64k parallel envs (the configuration BASELINE.json's metric is quoted on; fits one GPU). "
                          "8192 = the per-GPU shard of configs[4] (65 536 envs on 8 GPUs)")
     ap.add_argument("--workload", choices=["physics", "train", "auto"], default="auto")
+    ap.add_argument("--family", type=int, default=0, help="SAC network family: 0 = reference shapes, 1 = 256x256 MLP")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per K steps")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample length (0 = skip)")
     ap.add_argument("--roofline-envs", type=int, default=1 << 22, help="bandwidth-regime size for the extra roofline point")
@@ -162,15 +163,20 @@ def main():
 
     graph = None
     if not args.no_graph:
-        graph = torch.cuda.CUDAGraph()
-        side = torch.cuda.Stream(device)
-        side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(graph, stream=side):
-                for k in range(K):
-                    step_fn(k)
-        torch.cuda.current_stream(device).wait_stream(side)
-        torch.cuda.synchronize(device)
+        try:
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    for k in range(K):
+                        step_fn(k)
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize(device)
+        except Exception as e:  # e.g. a collective that cannot be captured: fall back to eager launches
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize(device)
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier(world)

@@ -212,6 +212,12 @@ int tvc_sac_actor_apply(tvc_sac* sac, float grad_scale, void* stream);
 int tvc_sac_update(tvc_sac* sac, const float* s, const float* a, const float* r, const float* s2, const float* d,
                    const float* eps_next, const float* eps_new, float* losses_dev, void* stream);
 
+/* The fused nn.Linear kernel on its own: Y[M,N] = act(X[M,K] W[N,K]^T + b), act 0 none / 1 GELU / 2 ReLU
+ * (numerics tests against torch.nn.functional.linear, kernel benchmarks).  variant 0 = automatic choice,
+ * 1 = 64x64 LDS-tiled, 3 = skinny split-K. */
+int tvc_nn_linear_forward(const float* X, const float* W, const float* b, float* Y, int32_t M, int32_t N, int32_t K,
+                          int32_t act, int32_t variant, void* stream);
+
 /* critic forward q1(s,a), q2(s,a) for n <= batch_size rows (tests / diagnostics): q_dev float[2,n] */
 int tvc_sac_q_values(tvc_sac* sac, const float* s, const float* a, int32_t n, int32_t use_target, float* q_dev, void* stream);
 

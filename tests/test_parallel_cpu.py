@@ -1,0 +1,74 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the data-parallel plumbing (env sharding, flat gradient
+all-reduce + scale, parameter broadcast) that the GPU ranks use with RCCL."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tvc_ai_amd.parallel import GradSync, broadcast_parameters, max_over_ranks, shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for total in (65536, 32768, 4096, 1000, 7):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(r, world, total) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(2, 2, 10)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)
+        params = torch.randn(1000)
+        broadcast_parameters(params)           # everyone now holds rank 0's weights
+        grads = torch.arange(2000, dtype=torch.float32) * (rank + 1)
+        sync = GradSync()
+        n_policy = 1500
+        sync(grads[n_policy:])                 # critic slice, then actor slice: two calls per update
+        sync(grads[:n_policy])
+        # replica update with the folded 1/world scale (what the Adam kernel does with grad_scale)
+        new_params = params - 0.1 * (grads[:1000] * sync.grad_scale)
+        mx = max_over_ranks(float(rank + 1), torch.device("cpu"))
+        q.put((rank, params[:5].tolist(), grads[[0, 1499, 1500, 1999]].tolist(), new_params.sum().item(), sync.calls,
+               sync.bytes, mx))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_sync():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, p0, g0, s0, c0, b0, m0), (r1, p1, g1, s1, c1, b1, m1) = res
+    assert p0 == p1                                   # broadcast made the replicas identical
+    assert g0 == g1 == [0.0, 1499 * 3.0, 1500 * 3.0, 1999 * 3.0]   # sum over ranks of i*(rank+1)
+    assert abs(s0 - s1) < 1e-3                        # identical update on every replica
+    assert c0 == c1 == 2 and b0 == b1 == 2000 * 4
+    assert m0 == m1 == 2.0

@@ -22,12 +22,15 @@ def main():
     meta = {}
     with open(path) as f:
         for row in csv.DictReader(f):
-            g = int(row.get("Grid_Size", row.get("Grid_Size_X", 0)) or 0)
-            wg = int(row.get("Workgroup_Size", row.get("Workgroup_Size_X", 0)) or 0)
+            if "Grid_Size_X" in row:
+                g = "x".join(str(int(row[f"Grid_Size_{a}"]) // max(1, int(row[f"Workgroup_Size_{a}"]))) for a in "XYZ")
+                wg = int(row["Workgroup_Size_X"])
+            else:
+                g, wg = row.get("Grid_Size", "?"), int(row.get("Workgroup_Size", 0) or 0)
             key = (short(row["Kernel_Name"]), g, wg)
             groups[key].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
             meta[key] = (row.get("VGPR_Count", "?"), row.get("SGPR_Count", "?"), row.get("LDS_Block_Size", "?"))
-    lines = ["| kernel | grid (threads) | block | calls | mean us | median us | min us | VGPR | SGPR | LDS B |",
+    lines = ["| kernel | grid (blocks x,y,z) | block | calls | mean us | median us | min us | VGPR | SGPR | LDS B |",
              "|---|---|---|---|---|---|---|---|---|---|"]
     for key, d in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
         v = meta[key]

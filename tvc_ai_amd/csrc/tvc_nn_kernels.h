@@ -187,6 +187,141 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     }
 }
 
+// ---- shared epilogue: bias, row table, pre-activation copy, activation, residual, act' multiply
+struct GemmEpi {
+    float* C; const float* bias; float* Zout; const float* Radd; const float* dZ; float* colsum;
+};
+__device__ __forceinline__ GemmEpi gemm_epi_ptrs(const GemmArgs& g, long z) {
+    GemmEpi e;
+    e.C = g.C + z * g.gC;
+    e.bias = g.bias ? g.bias + z * g.gBias : nullptr;
+    e.Zout = g.Zout ? g.Zout + z * g.gZ : nullptr;
+    e.Radd = g.Radd ? g.Radd + z * g.gR : nullptr;
+    e.dZ = g.dactZ ? g.dactZ + z * g.gDZ : nullptr;
+    e.colsum = g.colsum ? g.colsum + z * g.gCol : nullptr;
+    return e;
+}
+__device__ __forceinline__ float gemm_epi_value(const GemmArgs& g, const GemmEpi& e, float acc, int row, int col) {
+    float v = acc + (e.bias ? e.bias[col] : 0.0f);
+    if (g.rowtab) v += g.rowtab[(long)min(row, g.rowtab_rows - 1) * g.N + col];
+    const long o = (long)row * g.ldc + col;
+    if (e.Zout) e.Zout[o] = v;
+    v = act_f(v, g.act);
+    if (e.Radd) v += e.Radd[o];
+    if (e.dZ) v *= act_grad(e.dZ[o], g.dact);
+    return v;
+}
+
+// ------------------------------------------------------------------ skinny GEMM (update path, M = batch = a few hundred)
+// 32x32 output tile per workgroup; the four waves split K and stream their MFMA fragments straight from global /
+// L2 into registers (no LDS staging, no barrier in the k-loop: with so few rows there is no reuse to stage for,
+// and the 64x64 LDS-tiled kernel above is latency-bound at ~1 us per k-tile on these shapes); partial tiles are
+// summed through LDS once at the end.
+// FAST: every fragment load is in range and 16-byte aligned (M, N multiples of 32, K a multiple of 16, k-contiguous
+// operands with ld % 4 == 0): loads are unconditional.  Otherwise addresses are clamped into range and the value is
+// zero-selected AFTER the load -- never a branch around a load (hipcc would wait vmcnt(0) per element, guide 5 item 4c).
+template <bool A_KC, bool B_KC, bool FAST>
+__global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g) {
+    __shared__ float red[4][32 * 33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const long z = blockIdx.z;
+    const float* A = g.A + z * g.gA;
+    const float* B = g.B + z * g.gB;
+    const int ksteps = (g.K + 15) / 16;
+    const int spw = (ksteps + 3) / 4;
+    const int s_begin = wave * spw, s_end = min(ksteps, s_begin + spw);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, kq = (lane >> 4) * 4;
+    constexpr int CH = 4;  // k-steps per chunk: the fragment loads of a chunk are all in flight before its 64 MFMAs
+    for (int sc = s_begin; sc < s_end; sc += CH) {
+        float a[CH][2][4], b[CH][2][4];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const bool live = sc + u < s_end;
+            const int k0 = (live ? sc + u : s_begin) * 16 + kq;  // dead steps re-read a valid step and are zeroed
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = m0 + i * 16 + l15, col = n0 + i * 16 + l15;
+                const int rowc = FAST ? row : min(row, g.M - 1), colc = FAST ? col : min(col, g.N - 1);
+                if (A_KC && FAST) {
+                    const float4 v = *reinterpret_cast<const float4*>(A + (long)rowc * g.lda + k0);
+                    a[u][i][0] = v.x; a[u][i][1] = v.y; a[u][i][2] = v.z; a[u][i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int kc = FAST ? k0 + j : min(k0 + j, g.K - 1);
+                        const float v = A_KC ? A[(long)rowc * g.lda + kc] : A[(long)kc * g.lda + rowc];
+                        a[u][i][j] = (FAST || (row < g.M && k0 + j < g.K)) ? v : 0.0f;
+                    }
+                }
+                if (B_KC && FAST) {
+                    const float4 v = *reinterpret_cast<const float4*>(B + (long)colc * g.ldb + k0);
+                    b[u][i][0] = v.x; b[u][i][1] = v.y; b[u][i][2] = v.z; b[u][i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int kc = FAST ? k0 + j : min(k0 + j, g.K - 1);
+                        const float v = B_KC ? B[(long)colc * g.ldb + kc] : B[(long)kc * g.ldb + colc];
+                        b[u][i][j] = (FAST || (col < g.N && k0 + j < g.K)) ? v : 0.0f;
+                    }
+                }
+                if (!live) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { a[u][i][j] = 0.0f; b[u][i][j] = 0.0f; }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i][j4], b[u][j][j4], acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][(i * 16 + (lane >> 4) * 4 + r) * 33 + j * 16 + l15] = acc[i][j][r];
+    __syncthreads();
+    const GemmEpi e = gemm_epi_ptrs(g, z);
+    const int rl = tid >> 3, cl = (tid & 7) * 4;  // 32 rows x 8 column quads
+    const int row = m0 + rl;
+    float out[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = n0 + cl + c;
+        const int o = rl * 33 + cl + c;
+        float v = red[0][o] + red[1][o] + red[2][o] + red[3][o];
+        out[c] = 0.0f;
+        if (row < g.M && col < g.N) {
+            v = gemm_epi_value(g, e, v, row, col);
+            e.C[(long)row * g.ldc + col] = v;
+            out[c] = v;
+        }
+    }
+    if (e.colsum) {  // column sums of the final tile (bias gradient): reduce the 32 rows through LDS
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[0][rl * 33 + cl + c] = out[c];
+        __syncthreads();
+        if (tid < 32 && n0 + tid < g.N) {
+            float sum = 0.0f;
+            for (int r = 0; r < 32; ++r) sum += red[0][r * 33 + tid];
+            atomicAdd(&e.colsum[n0 + tid], sum);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ LayerNorm (eps 1e-5, biased variance): one wave per row
 struct LnArgs {
     const float* X; float* Y; const float* gamma; const float* beta;
@@ -240,7 +375,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(LnArgs a) {
 
 // backward of Y = LN(X): dX = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dY * gamma.
 // Optional fusions: dX *= act'(Zp) (the LN input was act(Zp)); column sums of the result (bias grad of the
-// producing Linear); dgamma / dbeta accumulated with float atomics (16 rows per block).
+// producing Linear); dgamma / dbeta accumulated with float atomics (8 rows per block).
 struct LnBwdArgs {
     const float* dY; const float* X; const float* gamma; const float* mean; const float* rstd;
     float* dX; float* dgamma; float* dbeta;
@@ -262,8 +397,8 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(LnBwdArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) { dg[i] = 0.f; db[i] = 0.f; cs[i] = 0.f; }
-    const int row_base = blockIdx.x * 16 + wave * 4;
-    for (int rr = 0; rr < 4; ++rr) {
+    const int row_base = blockIdx.x * 8 + wave * 2;  // 2 rows per wave: short dependency chain, 32+ blocks at batch 256
+    for (int rr = 0; rr < 2; ++rr) {
         const int row = row_base + rr;
         if (row >= a.M) break;
         const long off = z * a.gA + (long)row * a.N;
@@ -360,19 +495,20 @@ __global__ void __launch_bounds__(256) head_bwd_dx_kernel(HeadBwdArgs a) {
     }
 }
 __global__ void __launch_bounds__(256) head_bwd_dw_kernel(HeadBwdArgs a) {
-    // one thread per (j, k): loops over the M rows (M = batch, a few hundred)
+    // thread per (j, k), blockIdx.z = chunk of 32 rows; partial sums meet through float atomics
     const long z = blockIdx.y;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= a.NO * a.K) return;
     const int j = idx / a.K, k = idx - j * a.K;
+    const int m_begin = blockIdx.z * 32, m_end = min(a.M, m_begin + 32);
     float s = 0.f, sb = 0.f;
-    for (int m = 0; m < a.M; ++m) {
+    for (int m = m_begin; m < m_end; ++m) {
         const float dv = a.dOut[z * a.gD + (long)m * a.NO + j];
         s += dv * a.X[z * a.gX + (long)m * a.K + k];
         sb += dv;
     }
-    a.dW[z * a.gW + idx] += s;
-    if (k == 0) a.db[z * a.gB + j] += sb;
+    atomicAdd(&a.dW[z * a.gW + idx], s);
+    if (k == 0) atomicAdd(&a.db[z * a.gB + j], sb);
 }
 
 // ------------------------------------------------------------------ optimiser

@@ -132,7 +132,29 @@ struct Ctx {
     std::vector<long> gY;                       // group stride (elements) per buffer
 };
 
+static int g_force_variant = 0;  // diagnostics: 0 auto, 1 = 64x64 LDS-tiled, 3 = skinny split-K
+
 static void launch_gemm(bool a_kc, bool b_kc, const GemmArgs& g, int G, hipStream_t st) {
+    const bool aligned = ((g.lda & 3) == 0) && ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+    const int fv = g_force_variant;
+    if ((fv == 3 || (fv == 0 && (long)g.M * g.N <= 512L * 512L)) && g.A2 == nullptr) {
+        // update path (batch of a few hundred rows): latency-optimised split-K kernel
+        dim3 grid((g.N + 31) / 32, (g.M + 31) / 32, G), block(256);
+        const bool fast = aligned && (g.M % 32) == 0 && (g.N % 32) == 0 && (g.K % 16) == 0 &&
+                          ((g.gA | g.gB) & 3) == 0;
+#define TVC_SKINNY(AK, BK)                                                                               \
+    do {                                                                                                 \
+        if (fast) hipLaunchKernelGGL((gemm_skinny_kernel<AK, BK, true>), grid, block, 0, st, g);         \
+        else hipLaunchKernelGGL((gemm_skinny_kernel<AK, BK, false>), grid, block, 0, st, g);             \
+    } while (0)
+        if (a_kc && b_kc) TVC_SKINNY(true, true);
+        else if (a_kc && !b_kc) TVC_SKINNY(true, false);
+        else if (!a_kc && b_kc) TVC_SKINNY(false, true);
+        else TVC_SKINNY(false, false);
+#undef TVC_SKINNY
+        return;
+    }
     dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, G), block(256);
     if (a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, st, g);
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, st, g);
@@ -224,7 +246,7 @@ static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, l
             if (Gr) {
                 HeadBwdArgs aw = a;
                 aw.gW = gG; aw.gB = gG;
-                hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((o.out_dim * o.in_dim + 255) / 256, G), dim3(256), 0, st, aw);
+                hipLaunchKernelGGL(head_bwd_dw_kernel, dim3((o.out_dim * o.in_dim + 255) / 256, G, (M + 31) / 32), dim3(256), 0, st, aw);
             }
         } else if (o.type == OP_LN) {
             LnBwdArgs a{};
@@ -237,7 +259,7 @@ static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, l
             a.gA = c.gY[out]; a.gP = Gr ? gG : gP; a.gS = M;
             // gamma is read with the PARAMETER stride, dgamma written with the GRADIENT stride: both nets use the
             // same block layout, so the strides coincide whenever Gr != nullptr (gG == gP is asserted at create)
-            dim3 grid((M + 15) / 16, G), block(256);
+            dim3 grid((M + 7) / 8, G), block(256);
             if (o.out_dim == 256) hipLaunchKernelGGL((layernorm_bwd_kernel<4>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((layernorm_bwd_kernel<8>), grid, block, 0, st, a);
         } else {  // LINEAR: c.dY[out] already holds dZ (act' and bias column sums were fused by its writer)
@@ -714,6 +736,20 @@ int tvc_sac_update(tvc_sac* h, const float* s, const float* a, const float* r, c
     if (int e = tvc_sac_critic_apply(h, 1.0f, stream)) return e;
     if (int e = tvc_sac_actor_grads(h, s, eps_new, losses, stream)) return e;
     return tvc_sac_actor_apply(h, 1.0f, stream);
+}
+
+// Y[M,N] = act(X[M,K] W[N,K]^T + b): the fused Linear kernel on its own (numerics tests and kernel benchmarks).
+// variant: 0 auto, 1 = 64x64 LDS-tiled, 3 = skinny split-K.
+int tvc_nn_linear_forward(const float* X, const float* W, const float* b, float* Y, int32_t M, int32_t N, int32_t K, int32_t act,
+                          int32_t variant, void* stream) {
+    if (!X || !W || !Y || M < 1 || N < 1 || K < 1) return tvc::set_error(TVC_EINVAL, "bad argument");
+    GemmArgs g{};
+    g.A = X; g.B = W; g.C = Y; g.M = M; g.N = N; g.K = K; g.K1 = K; g.lda = K; g.ldb = K; g.ldc = N; g.bias = b; g.act = act;
+    g_force_variant = variant;
+    launch_gemm(true, true, g, 1, (hipStream_t)stream);
+    g_force_variant = 0;
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int tvc_sac_q_values(tvc_sac* h, const float* s, const float* a, int32_t n, int32_t use_target, float* q, void* stream) {

@@ -161,16 +161,19 @@ class VecRocketTVCEnv:
         nat.check(self.L.tvc_env_reset(self._h, nat.ptr(mask), 1 if hard else 0, self.obs.data_ptr(), self._stream()))
         return self.obs, {}
 
-    def step(self, actions: torch.Tensor):
+    def step(self, actions: torch.Tensor, out_obs: Optional[torch.Tensor] = None):
+        """out_obs: optional [N,10] tensor that receives the observation instead of self.obs (lets a caller
+        keep the previous observation alive without a copy)."""
+        obs = self.obs if out_obs is None else out_obs
         if actions.shape != (self.num_envs, ACT_DIM):
             raise ValueError(f"actions must be [{self.num_envs},{ACT_DIM}], got {tuple(actions.shape)}")
         if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
             actions = actions.to(device=self.device, dtype=torch.float32).contiguous()
-        nat.check(self.L.tvc_env_step(self._h, actions.data_ptr(), self.obs.data_ptr(), self.rew.data_ptr(),
+        nat.check(self.L.tvc_env_step(self._h, actions.data_ptr(), obs.data_ptr(), self.rew.data_ptr(),
                                       self.term.data_ptr(), self.trunc.data_ptr(), nat.ptr(self.final_obs),
                                       self._stream()))
         info = {"final_observation": self.final_obs} if self.final_obs is not None else {}
-        return self.obs, self.rew, self.term, self.trunc, info
+        return obs, self.rew, self.term, self.trunc, info
 
     def step_many(self, actions: torch.Tensor, out=None):
         """T steps in one launch with pre-supplied actions [T,N,2] (tests/benchmark.py:40-60 procedure)."""

@@ -1,0 +1,102 @@
+"""Vectorised training loop over the HIP env and SAC kernels: the counterpart of
+StateOfTheArtTrainer.run_episode (scripts/train.py:535-620) for N envs per GPU.
+
+One ``step()`` = policy act on N observations -> vector env step -> replay insert (true next observation,
+done = terminated|truncated) -> [uniform sample of B rows -> one SAC update].  Everything is enqueued on the
+current HIP stream with no host synchronisation, so K steps can be captured in one hipGraph.
+"""
+import time
+from typing import Optional
+
+import torch
+
+from .agent import NativeSAC, ReplayBuffer, sac_cfg
+from .env import VecRocketTVCEnv
+from .parallel import GradSync, broadcast_parameters
+
+
+class VecTrainer:
+    def __init__(self, num_envs: int, device="cuda:0", config: Optional[dict] = None, family: int = 0, batch_size: int = 256,
+                 replay_capacity: int = 1_000_000, seed: int = 42, rank: int = 0, world: int = 1, updates_per_step: int = 1,
+                 max_episode_steps: int = 1000, **env_over):
+        self.device = torch.device(device)
+        self.n, self.B, self.world, self.rank = num_envs, batch_size, world, rank
+        self.updates_per_step = updates_per_step
+        self.env = VecRocketTVCEnv(num_envs, device=self.device, config=config, max_episode_steps=max_episode_steps,
+                                   seed=seed, env_id_offset=rank * num_envs, want_final_obs=True, **env_over)
+        self.sac = NativeSAC(sac_cfg(family, batch_size=batch_size, max_act_rows=num_envs), device=self.device, seed=seed)
+        broadcast_parameters(self.sac.params)  # identical replicas (rank 0's initialisation)
+        self.rb = ReplayBuffer(replay_capacity, 10, 2, device=self.device, seed=seed * 1000003 + rank)
+        self.sync = GradSync() if world > 1 else None
+        d, n, B = self.device, num_envs, batch_size
+        self.obs = [torch.empty((n, 10), device=d), torch.empty((n, 10), device=d)]
+        self.cur = 0
+        self.act = torch.empty((n, 2), device=d)
+        self.mean = torch.empty((n, 2), device=d)
+        self.ls = torch.empty((n, 2), device=d)
+        self.eps_act = torch.empty((n, 2), device=d)
+        self.eps1 = torch.empty((B, 2), device=d)
+        self.eps2 = torch.empty((B, 2), device=d)
+        self.batch = (torch.empty((B, 10), device=d), torch.empty((B, 2), device=d), torch.empty((B,), device=d),
+                      torch.empty((B, 10), device=d), torch.empty((B,), device=d))
+        torch.manual_seed(seed + rank)  # default CUDA generator: hipGraph-capturable normal draws
+        o, _ = self.env.reset()
+        self.obs[0].copy_(o)
+        self.steps = 0
+
+    def close(self):
+        self.env.close()
+        self.sac.close()
+        self.rb.close()
+
+    def collect(self):
+        """act + env step + replay insert"""
+        cur, nxt = self.obs[self.cur], self.obs[1 - self.cur]
+        self.eps_act.normal_()
+        self.sac.act(cur, self.eps_act, out=(self.act, self.mean, self.ls))
+        o, rew, term, trunc, info = self.env.step(self.act, out_obs=nxt)
+        self.rb.insert(cur, self.act, rew, info["final_observation"], term, trunc)
+        self.cur = 1 - self.cur
+
+    def learn(self):
+        self.rb.sample(self.B, out=self.batch)
+        self.eps1.normal_()
+        self.eps2.normal_()
+        s, a, r, s2, d = self.batch
+        gs = self.sync.grad_scale if self.sync is not None else 1.0
+        return self.sac.update(s, a, r, s2, d, self.eps1, self.eps2, all_reduce=self.sync, grad_scale=gs)
+
+    def step(self, learn: bool = True):
+        self.collect()
+        if learn:
+            for _ in range(self.updates_per_step):
+                self.learn()
+        self.steps += 1
+
+    def stats(self):
+        return {"env_steps": self.steps * self.n, "updates": self.steps * self.updates_per_step,
+                "losses": self.sac.losses.cpu().tolist()}
+
+
+def bench_train(args, world, rank, device):
+    """bench.py workload 'train': returns the step function and the env (for the roofline leg)."""
+    family = getattr(args, "family", 0)
+    tr = VecTrainer(args.envs_per_gpu, device=device, family=family, batch_size=256, replay_capacity=1_000_000, seed=42,
+                    rank=rank, world=world, updates_per_step=1)
+    fam = "reference shapes (seq-len-1 transformer actor 2.26M trainable params, 512/256 GELU+LN critics)" if family == 0 \
+        else "256x256 ReLU MLP actor/critics"
+    return {"step_fn": lambda k: tr.step(True), "env": tr.env, "trainer": tr,
+            "extra": {"updates_per_step": 1.0, "sac": {"family": fam, "batch": 256, "replay_capacity": 1_000_000,
+                                                      "utd": "1 update per vector step", "dtype": "f32 MFMA"}}}
+
+
+def smoke():
+    """tiny end-to-end train loop on cuda:0 (called from __graft_entry__.smoke)"""
+    tr = VecTrainer(256, device="cuda:0", family=0, batch_size=64, replay_capacity=4096, seed=1)
+    for _ in range(6):
+        tr.step(True)
+    torch.cuda.synchronize()
+    st = tr.stats()
+    assert all(torch.isfinite(torch.tensor(st["losses"]))), st
+    tr.close()
+    return st
