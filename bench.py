@@ -25,6 +25,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak (= fp32 vector peak)
 # Algorithmic bytes of one env-step through the single-step kernel (DESIGN.md "K1 traffic"):
 # reads  dyn 13 + prev_action 2 + aux 2 + episode 1 + reward window 10 + action 2        = 30 words
 # writes dyn 13 + prev_action 2 + aux 2 + episode 1 + window slot 1 + obs 10 + reward 1  = 30 words + 2 flag bytes
@@ -116,9 +117,48 @@ def cpu_baseline(seconds):
     with ThreadPoolExecutor(cores) as ex:
         total = sum(ex.map(work, vecs))
     dt = time.perf_counter() - t0
-    return {"value": total / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{total} env-steps: {cores} threads x 64 envs, oracle/tvc_oracle.c fp64, "
-                      f"contact+auto-reset, {dt:.1f} s"}
+    out = {"value": total / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{total} env-steps: {cores} threads x 64 envs, oracle/tvc_oracle.c fp64, "
+                     f"contact+auto-reset, {dt:.1f} s (env half only; learner half below)"}
+    # learner half: the eager-PyTorch restatement of _update_sac (oracle/sac_torch.py, reference shapes, B = 256)
+    try:
+        from oracle import sac_torch as st
+        torch.set_num_threads(cores)
+        g = torch.Generator().manual_seed(0)
+        shapes = {"input_embedding.weight": (256, 10), "input_embedding.bias": (256,), "feature_norm.weight": (256,),
+                  "feature_norm.bias": (256,), "policy_head.0.weight": (512, 256), "policy_head.0.bias": (512,),
+                  "policy_head.2.weight": (512,), "policy_head.2.bias": (512,), "policy_head.4.weight": (512, 512),
+                  "policy_head.4.bias": (512,), "policy_head.6.weight": (512,), "policy_head.6.bias": (512,),
+                  "policy_head.8.weight": (4, 512), "policy_head.8.bias": (4,)}
+        for l in range(4):
+            p = f"transformer_encoder.layers.{l}."
+            shapes.update({p + "self_attn.in_proj_weight": (768, 256), p + "self_attn.in_proj_bias": (768,),
+                           p + "self_attn.out_proj.weight": (256, 256), p + "self_attn.out_proj.bias": (256,),
+                           p + "linear1.weight": (512, 256), p + "linear1.bias": (512,), p + "linear2.weight": (256, 512),
+                           p + "linear2.bias": (256,), p + "norm1.weight": (256,), p + "norm1.bias": (256,),
+                           p + "norm2.weight": (256,), p + "norm2.bias": (256,)})
+        mk = lambda sh: (torch.randn(sh, generator=g) / (sh[1] ** 0.5 if len(sh) > 1 else 10.0)) + (1.0 if len(sh) == 1 else 0.0)
+        P = {k: mk(v) for k, v in shapes.items()}
+        qs = {"0.weight": (512, 12), "0.bias": (512,), "2.weight": (512,), "2.bias": (512,), "4.weight": (256, 512),
+              "4.bias": (256,), "6.weight": (256,), "6.bias": (256,), "8.weight": (1, 256), "8.bias": (1,)}
+        Q1, Q2 = {k: mk(v) for k, v in qs.items()}, {k: mk(v) for k, v in qs.items()}
+        orc = st.SacOracle(P, Q1, Q2)
+        B = 256
+        batch = (torch.randn(B, 10), torch.rand(B, 2) * 2 - 1, torch.randn(B), torch.randn(B, 10), torch.zeros(B))
+        e1, e2 = torch.randn(B, 2), torch.randn(B, 2)
+        for _ in range(2):
+            orc.update(*batch, e1, e2)
+        t0 = time.perf_counter()
+        n_up = 0
+        while time.perf_counter() - t0 < max(2.0, seconds * 0.4):
+            orc.update(*batch, e1, e2)
+            n_up += 1
+        out["sac_updates_per_s"] = n_up / (time.perf_counter() - t0)
+        out["sac_sample"] = f"{n_up} updates, eager PyTorch fp32 restatement, {cores} threads, B=256, reference shapes"
+    except Exception as e:
+        out["sac_updates_per_s"] = None
+        out["sac_sample"] = f"failed: {e}"
+    return out
 
 
 def main():
@@ -219,42 +259,7 @@ def main():
     out.update(extra)
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: env_step_kernel (HBM-bound: ~2.7 flop/B)
-        if workload == "physics":
-            # the timed region holds exactly K launches of this one kernel: average launch duration =
-            # HIP-event time of the region / K (agrees with rocprofv3's per-dispatch average, profiles/)
-            mean_us = med_us = dev_us_per_step
-        else:
-            mean_us, med_us, _ = kernel_event_times(extra_env_only(env, device), 200, device)
-        ach = ENV_STEP_BYTES * n / (mean_us * 1e-6) / 1e9
-        pmc = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pj = json.load(f)
-            pmc = pj.get(str(n), {}).get("hbm_bytes_per_launch")
-        except Exception:
-            pmc = None
-        out["roofline"] = {"bound": "hbm", "kernel": "env_step_kernel<W10>", "achieved": ach, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc,
-                           "launch_us_mean": mean_us, "launch_us_median": med_us,
-                           "algorithmic_bytes_per_launch": ENV_STEP_BYTES * n}
-        # the same kernel in its bandwidth regime (H3: at 8 192 envs one launch moves 2 MB and is latency-bound)
-        try:
-            nb = args.roofline_envs
-            big = VecRocketTVCEnv(nb, device=device, seed=7)
-            big.reset()
-            ab = (torch.rand((4, nb, 2), device=device) * 2 - 1).contiguous()
-            for k in range(10):
-                big.step(ab[k % 4])
-            m2, md2, mn2 = kernel_event_times(lambda k: big.step(ab[k % 4]), 50, device)
-            ach2 = ENV_STEP_BYTES * nb / (m2 * 1e-6) / 1e9
-            out["roofline_large_n"] = {"envs": nb, "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": ach2 / HBM_PEAK_GBS, "launch_us_mean": m2,
-                                       "env_steps_per_s": nb / (m2 * 1e-6)}
-            big.close()
-            del big, ab
-        except Exception as e:  # never lose the headline line to the optional point
-            out["roofline_large_n"] = {"error": str(e)}
+        out.update(roofline_report(args, workload, n, step_fn if workload == "physics" else None, dev_us_per_step, device))
         if args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
@@ -264,10 +269,86 @@ def main():
         dist.destroy_process_group()
 
 
-def extra_env_only(env, device):
-    n = env.num_envs
-    acts = (torch.rand((8, n, 2), device=device) * 2 - 1).contiguous()
-    return lambda k: env.step(acts[k % 8])
+def graph_time_us(fn, reps, device, rounds=5):
+    """Average duration of one launch: `reps` back-to-back launches captured in a hipGraph, HIP events on the
+    stream they run on, best of `rounds` (what rocprofv3's per-dispatch average agrees with, profiles/)."""
+    for _ in range(3):
+        fn(0)
+    torch.cuda.synchronize(device)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for k in range(reps):
+                fn(k)
+    torch.cuda.current_stream(device).wait_stream(side)
+    torch.cuda.synchronize(device)
+    best = float("inf")
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize(device)
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    return best
+
+
+def pmc_traffic(n):
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get("env_step_kernel", {}).get(str(n), {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def integrator_roofline(n, device, us=None):
+    """HBM roofline of env_step_kernel at n envs (fresh env, pre-generated actions)."""
+    from tvc_ai_amd import VecRocketTVCEnv
+    if us is None:
+        env = VecRocketTVCEnv(n, device=device, seed=7)
+        env.reset()
+        acts = (torch.rand((8, n, 2), device=device) * 2 - 1).contiguous()
+        for k in range(40):  # spread the envs over episode phases
+            env.step(acts[k % 8])
+        us = graph_time_us(lambda k: env.step(acts[k % 8]), 50, device)
+        env.close()
+    ach = ENV_STEP_BYTES * n / (us * 1e-6) / 1e9
+    return {"bound": "hbm", "kernel": "env_step_kernel<W10,noDR>", "envs": n, "achieved": ach, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(n), "launch_us": us,
+            "algorithmic_bytes_per_launch": ENV_STEP_BYTES * n, "env_steps_per_s": n / (us * 1e-6)}
+
+
+def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device):
+    rep = {}
+    if workload == "physics":
+        # the timed region holds exactly K launches of this one kernel: launch duration = HIP-event time / K
+        rep["roofline"] = integrator_roofline(n, device, us=dev_us_per_step)
+    else:
+        # dominant kernel of the train loop = the fused Linear GEMM of the acting pass (M = envs, 256x256 layers:
+        # 8 of its 13 GEMMs), fp32-input MFMA (v_mfma_f32_16x16x4_f32), dense peak 157.3 TFLOP/s
+        from tvc_ai_amd import _native as nat
+        L = nat.load()
+        M, N, K = n, 256, 256
+        X = torch.randn(M, K, device=device)
+        W = torch.randn(N, K, device=device) / 16
+        b = torch.zeros(N, device=device)
+        Y = torch.empty(M, N, device=device)
+        st = torch.cuda.current_stream(device)
+        us = graph_time_us(lambda k: L.tvc_nn_linear_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, N, K, 0, 0,
+                                                             torch.cuda.current_stream(device).cuda_stream), 20, device)
+        tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
+        rep["roofline"] = {"bound": "mfma", "kernel": "tvcnn::gemm_kernel<true,true> (Linear 256->256, M = envs)", "achieved": tf,
+                           "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None,
+                           "launch_us": us, "flops_per_launch": 2.0 * M * N * K, "dtype": "f32 in / f32 acc MFMA"}
+        del X, W, b, Y
+        rep["roofline_integrator"] = integrator_roofline(n, device)
+    try:  # the integrator in its bandwidth regime (H3: small batches are launch/latency-bound)
+        rep["roofline_integrator_large_n"] = integrator_roofline(args.roofline_envs, device)
+    except Exception as e:  # never lose the headline line to the optional point
+        rep["roofline_integrator_large_n"] = {"error": str(e)}
+    return rep
 
 
 if __name__ == "__main__":

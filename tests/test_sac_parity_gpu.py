@@ -214,3 +214,26 @@ def test_agent_surface_update_accepts_bool_dones():
     assert agent.select_algorithm() == "sac"
     agent.update_performance("sac", 12.0)
     assert list(agent.performance_history["sac"]) == [12.0]
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 512, 256), (300, 200, 37), (8192, 256, 256), (64, 12, 512), (1000, 256, 12)])
+def test_fused_linear_kernel_vs_torch_fp32(M, N, K):
+    """Both GEMM kernels (64x64 LDS-tiled, skinny split-K) against torch.nn.functional.linear in fp32, ragged
+    shapes included; MFMA f32 is an exact fma chain, so only the summation order differs (<= 1e-5 * sqrt(K))."""
+    import ctypes as C
+    from tvc_ai_amd import _native as nat
+    L = nat.load()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    X = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    for act, fn in ((0, lambda t: t), (1, torch.nn.functional.gelu), (2, torch.relu)):
+        ref = fn(torch.nn.functional.linear(X, W, b))
+        for variant in (1, 3):
+            if variant == 3 and M * N > 512 * 512:
+                continue
+            Y = torch.full((M, N), float("nan"), device="cuda")
+            nat.check(L.tvc_nn_linear_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, N, K, act, variant,
+                                              torch.cuda.current_stream().cuda_stream))
+            err = (Y - ref).abs().max().item()
+            assert err <= 1e-5 * max(1.0, K ** 0.5), (M, N, K, act, variant, err)
