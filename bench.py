@@ -202,7 +202,10 @@ def main():
     torch.cuda.synchronize(device)
 
     graph = None
-    if not args.no_graph:
+    use_graph = not args.no_graph and not (world > 1 and workload == "train")
+    # multi-GPU train: the two gradient all-reduces (RCCL) sit between kernel phases; they are issued eagerly
+    # rather than captured (collective capture is not something a 1-GPU gpurun box can validate)
+    if use_graph:
         try:
             graph = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream(device)

@@ -187,6 +187,11 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params_dev, fl
                    float* adam_v_dev, const float* pe_table_host, tvc_sac** out);
 void tvc_sac_destroy(tvc_sac* sac);
 
+/* Re-derives what the library caches from the parameter buffer (the folded attention weights W_o W_v of the
+ * acting net).  tvc_sac_actor_apply does this itself; call it after writing parameters from the host side
+ * (initialisation, checkpoint load, parameter broadcast). */
+int tvc_sac_sync_derived(tvc_sac* sac, void* stream);
+
 /* Policy part of get_action (agent/...:765-789) for n rows: mean/log_std (clamped to [-20,2]) and
  * action = clamp(mean + exp(log_std) * eps, -1, 1); eps_dev NULL = deterministic (action = clamp(mean)).
  * obs_dev float[n,obs]; act_dev float[n,A]; mean_dev / logstd_dev float[n,A] or NULL. */

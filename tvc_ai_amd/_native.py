@@ -77,6 +77,7 @@ SIGNATURES.update({
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tvc_sac_create": (C.c_int, [C.POINTER(SacCfg), C.c_int32, _VP, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "tvc_sac_destroy": (None, [_VP]),
+    "tvc_sac_sync_derived": (C.c_int, [_VP, _VP]),
     "tvc_sac_act": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP]),
     "tvc_sac_critic_grads": (C.c_int, [_VP] + [_VP] * 8),
     "tvc_sac_critic_apply": (C.c_int, [_VP, C.c_float, _VP]),

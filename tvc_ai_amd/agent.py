@@ -161,12 +161,18 @@ class NativeSAC:
     def sync_targets(self):
         n0, nc = self.n_policy, self.n_critic
         self.params[n0 + 2 * nc:n0 + 4 * nc].copy_(self.params[n0:n0 + 2 * nc])
+        self.sync_derived()
+
+    def sync_derived(self):
+        """call after writing `params` from the host side (folded acting weights are cached in the handle)"""
+        nat.check(self.L.tvc_sac_sync_derived(self._h, self._stream()))
 
     def load_named(self, tensors: Dict[str, torch.Tensor]):
         """native names -> values"""
         for k, v in tensors.items():
             dst = self.view(k)
             dst.copy_(torch.as_tensor(v, dtype=torch.float32).reshape(dst.shape))
+        self.sync_derived()
 
     def load_reference_state(self, net: str, state_dict: Dict[str, torch.Tensor]):
         """Import one reference net's state_dict (net in policy, q1, q2, target_q1, target_q2)."""
@@ -183,6 +189,7 @@ class NativeSAC:
             if name not in self.index:
                 raise KeyError(f"{net}.{k} has no native tensor ({name})")
             self.view(name).copy_(v.reshape(self.view(name).shape))
+        self.sync_derived()
 
     def export_reference_state(self, net: str) -> Dict[str, torch.Tensor]:
         """Reference-keyed state_dict of one net (checkpoint compatibility, agent/...:1098-1141)."""

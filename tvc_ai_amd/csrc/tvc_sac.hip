@@ -20,6 +20,7 @@ namespace {
 enum { OP_LINEAR = 0, OP_LN = 1, OP_HEAD = 2 };
 struct Op {
     int type, in_dim, out_dim, act, src, res, rowtab;
+    int ext = 0;  // 1: weight/bias offsets address the derived-weights buffer (folded W_o W_v of the acting net)
     long w, b;  // offsets inside the net's parameter block (LINEAR/HEAD: weight[out,in], bias[out]; LN: gamma, beta)
 };
 struct TensorInfo { std::string name; long off; int rows, cols; };
@@ -30,7 +31,8 @@ struct NetDef {
     int in_dim = 0;
     std::vector<int> buf_dim, res_consumer, producer, last_use;
     int add(int type, const std::string& name, int in, int out, int act, int src, int res, int rowtab) {
-        Op o{type, in, out, act, src, res, rowtab, 0, 0};
+        Op o;
+        o.type = type; o.in_dim = in; o.out_dim = out; o.act = act; o.src = src; o.res = res; o.rowtab = rowtab;
         o.w = n_params;
         if (type == OP_LN) {
             tensors.push_back({name + ".weight", n_params, out, 1}); n_params += out;
@@ -88,6 +90,43 @@ static NetDef build_actor(const tvc_sac_cfg& c) {
     n.finish();
     return n;
 }
+// Acting-only variant of the actor: at sequence length 1 attention is out_proj(v_proj(x)), two
+// back-to-back Linear layers with nothing in between, so for inference they fold into ONE 256x256 Linear with
+// W_ov = W_o W_v, b_ov = W_o b_v + b_o (re-derived after every actor update; the training net keeps them apart).
+struct FoldInfo { int layers = 0; long v_w = 0, v_b = 0, o_w = 0, o_b = 0, layer_stride = 0; int d = 0; };
+static NetDef derive_infer(const NetDef& a, FoldInfo& fi) {
+    NetDef n;
+    n.in_dim = a.in_dim;
+    std::vector<int> map(a.ops.size() + 1, -1);
+    map[0] = 0;
+    for (size_t i = 0; i < a.ops.size(); ++i) {
+        const Op& op = a.ops[i];
+        const bool fold = op.type == OP_LINEAR && op.act == ACT_NONE && op.res < 0 && op.in_dim == op.out_dim && !op.rowtab &&
+                          i + 1 < a.ops.size() && a.ops[i + 1].type == OP_LINEAR && a.ops[i + 1].act == ACT_NONE &&
+                          a.ops[i + 1].src == (int)i + 1 && a.ops[i + 1].res == op.src && a.ops[i + 1].in_dim == op.out_dim;
+        if (fold) {
+            const Op& o2 = a.ops[i + 1];
+            if (fi.layers == 0) { fi.v_w = op.w; fi.v_b = op.b; fi.o_w = o2.w; fi.o_b = o2.b; fi.d = op.in_dim; }
+            if (fi.layers == 1) fi.layer_stride = op.w - fi.v_w;
+            Op f = o2;
+            f.src = map[op.src]; f.res = map[op.src]; f.ext = 1;
+            f.w = (long)fi.layers * ((long)fi.d * fi.d + fi.d); f.b = f.w + (long)fi.d * fi.d;
+            n.ops.push_back(f);
+            map[i + 2] = (int)n.ops.size();
+            fi.layers += 1;
+            ++i;
+        } else {
+            Op c = op;
+            c.src = map[op.src];
+            c.res = op.res >= 0 ? map[op.res] : -1;
+            n.ops.push_back(c);
+            map[i + 1] = (int)n.ops.size();
+        }
+    }
+    n.finish();
+    return n;
+}
+
 static NetDef build_critic(const tvc_sac_cfg& c) {
     NetDef n;
     n.in_dim = c.obs_dim + c.act_dim;
@@ -164,7 +203,7 @@ static void launch_gemm(bool a_kc, bool b_kc, const GemmArgs& g, int G, hipStrea
 
 // forward of one net (G parameter groups batched through blockIdx.z).  X: [G?][M,in]; gX = 0 shares one input.
 static void net_forward(const NetDef& nd, const float* P, long gP, const float* X, long gX, int M, int G, Ctx& c, bool save,
-                        const float* pe, int pe_rows, hipStream_t st) {
+                        const float* pe, int pe_rows, hipStream_t st, const float* Pext = nullptr) {
     for (int i = 0; i < (int)nd.ops.size(); ++i) {
         const Op& o = nd.ops[i];
         const int out = i + 1;
@@ -172,10 +211,10 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
         const long gin = o.src == 0 ? gX : c.gY[o.src];
         if (o.type == OP_LINEAR) {
             GemmArgs g{};
-            g.A = in; g.B = P + o.w; g.C = c.Y[out];
+            g.A = in; g.B = (o.ext ? Pext : P) + o.w; g.C = c.Y[out];
             g.M = M; g.N = o.out_dim; g.K = o.in_dim; g.K1 = o.in_dim;
             g.lda = o.in_dim; g.ldb = o.in_dim; g.ldc = o.out_dim;
-            g.bias = P + o.b;
+            g.bias = (o.ext ? Pext : P) + o.b;
             if (o.rowtab && pe) { g.rowtab = pe; g.rowtab_rows = pe_rows; }
             g.Zout = (save && o.act != ACT_NONE) ? c.Z[out] : nullptr;
             g.act = o.act;
@@ -434,7 +473,9 @@ __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__
 struct tvc_sac {
     tvc_sac_cfg cfg;
     int device;
-    NetDef actor, critic;
+    NetDef actor, critic, actor_inf;
+    FoldInfo fold;
+    float* ov = nullptr;  // [layers][d*d + d] folded attention weights of the acting net
     long n_actor, n_critic;
     float *params, *grads, *adam_m, *adam_v;  // caller-owned
     void* slab = nullptr;                      // library-owned workspace
@@ -568,6 +609,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     if (!h) return tvc::set_error(TVC_ENOMEM, "host allocation failed");
     h->cfg = *cfg; h->device = device;
     h->actor = build_actor(*cfg); h->critic = build_critic(*cfg);
+    h->actor_inf = derive_infer(h->actor, h->fold);
     h->n_actor = h->actor.n_params; h->n_critic = h->critic.n_params;
     h->params = params; h->grads = grads; h->adam_m = adam_m; h->adam_v = adam_v;
     const int B = cfg->batch_size, A = cfg->act_dim, NA = cfg->max_act_rows;
@@ -576,6 +618,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     long bytes = ctx_bytes(h->actor, B, 1, true) + ctx_bytes(h->critic, B, 2, true) + 6L * NA * maxd * 4;
     bytes += (long)cfg->pe_rows * cfg->d_model * 4 + (long)B * (cfg->obs_dim + A) * 4 * 2 + (long)B * 64 + (1 << 16);
     bytes += 256L * (4 * (h->actor.buf_dim.size() + h->critic.buf_dim.size()) * 3 + 64);
+    bytes += (long)std::max(1, h->fold.layers) * ((long)h->fold.d * h->fold.d + h->fold.d + 4) * 4 + 1024;
     hipError_t he = hipMalloc(&h->slab, bytes);
     if (he != hipSuccess) {
         delete h;
@@ -585,7 +628,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     char* p = (char*)h->slab;
     ctx_alloc_train(h->actx, h->actor, B, 1, p);
     ctx_alloc_train(h->cctx, h->critic, B, 2, p);
-    if (ctx_alloc_infer(h->ictx, h->actor, NA, p) != 0) {
+    if (ctx_alloc_infer(h->ictx, h->actor_inf, NA, p) != 0) {
         (void)hipFree(h->slab);
         delete h;
         return tvc::set_error(TVC_EINVAL, "inference slot allocation failed");
@@ -599,6 +642,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     h->dq = (float*)carve(p, (long)B * 2 * 4);
     h->step = (int*)carve(p, 16);
     h->bc = (float*)carve(p, 16);
+    h->ov = (float*)carve(p, (long)std::max(1, h->fold.layers) * ((long)h->fold.d * h->fold.d + h->fold.d + 4) * 4);
     if ((long)(p - (char*)h->slab) > bytes) {
         (void)hipFree(h->slab);
         delete h;
@@ -635,8 +679,9 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
     hipStream_t st = (hipStream_t)stream;
     const int A = h->cfg.act_dim;
     // activation group strides depend on the row count actually used
-    for (size_t b = 1; b < h->ictx.gY.size(); ++b) h->ictx.gY[b] = (long)n * h->actor.buf_dim[b];
-    net_forward(h->actor, h->P_actor(), 0, obs, 0, n, 1, h->ictx, false, h->cfg.family == 0 ? h->pe : nullptr, h->cfg.pe_rows, st);
+    for (size_t b = 1; b < h->ictx.gY.size(); ++b) h->ictx.gY[b] = (long)n * h->actor_inf.buf_dim[b];
+    net_forward(h->actor_inf, h->P_actor(), 0, obs, 0, n, 1, h->ictx, false, h->cfg.family == 0 ? h->pe : nullptr, h->cfg.pe_rows, st,
+                h->ov);
     const float* head = h->ictx.Y.back();
     hipLaunchKernelGGL(sample_action_kernel, dim3((n * A + 255) / 256), dim3(256), 0, st, head, eps, act, mean, logstd, n, A, 1);
     TVC_HIP_CHECK(hipGetLastError());
@@ -718,11 +763,39 @@ int tvc_sac_actor_grads(tvc_sac* h, const float* s, const float* eps_new, float*
     return 0;
 }
 
+// W_ov = W_o W_v, b_ov = W_o b_v + b_o for every encoder layer of the acting net: two grouped launches
+static void refresh_folded(tvc_sac* h, hipStream_t st) {
+    const FoldInfo& f = h->fold;
+    if (f.layers == 0) return;
+    const int d = f.d;
+    const long ostride = (long)d * d + d;
+    GemmArgs g{};  // C[o, k] = sum_j Wo[o, j] Wv[j, k]
+    g.A = h->P_actor() + f.o_w; g.B = h->P_actor() + f.v_w; g.C = h->ov;
+    g.M = d; g.N = d; g.K = d; g.K1 = d; g.lda = d; g.ldb = d; g.ldc = d;
+    g.gA = f.layer_stride; g.gB = f.layer_stride; g.gC = ostride;
+    launch_gemm(true, false, g, f.layers, st);
+    GemmArgs b{};  // b_ov[o] = sum_j b_v[j] Wo[o, j] + b_o[o]   (1 x d row)
+    b.A = h->P_actor() + f.v_b; b.B = h->P_actor() + f.o_w; b.C = h->ov + (long)d * d;
+    b.M = 1; b.N = d; b.K = d; b.K1 = d; b.lda = d; b.ldb = d; b.ldc = d;
+    b.bias = h->P_actor() + f.o_b;
+    b.gA = f.layer_stride; b.gB = f.layer_stride; b.gC = ostride; b.gBias = f.layer_stride;
+    launch_gemm(true, true, b, f.layers, st);
+}
+
+int tvc_sac_sync_derived(tvc_sac* h, void* stream) {
+    if (!h) return tvc::set_error(TVC_EINVAL, "null argument");
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    refresh_folded(h, (hipStream_t)stream);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int tvc_sac_actor_apply(tvc_sac* h, float grad_scale, void* stream) {
     if (!h) return tvc::set_error(TVC_EINVAL, "null argument");
     TVC_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     adam_apply(h, h->P_actor(), h->G_actor(), 0, h->n_actor, 1, grad_scale, st);
+    refresh_folded(h, st);
     const long n = 2 * h->n_critic;
     hipLaunchKernelGGL(polyak_kernel, dim3((int)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, st, h->P_tq(), h->P_q(), n,
                        h->cfg.tau);

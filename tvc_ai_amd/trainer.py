@@ -26,6 +26,7 @@ class VecTrainer:
                                    seed=seed, env_id_offset=rank * num_envs, want_final_obs=True, **env_over)
         self.sac = NativeSAC(sac_cfg(family, batch_size=batch_size, max_act_rows=num_envs), device=self.device, seed=seed)
         broadcast_parameters(self.sac.params)  # identical replicas (rank 0's initialisation)
+        self.sac.sync_derived()
         self.rb = ReplayBuffer(replay_capacity, 10, 2, device=self.device, seed=seed * 1000003 + rank)
         self.sync = GradSync() if world > 1 else None
         d, n, B = self.device, num_envs, batch_size
