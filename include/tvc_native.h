@@ -194,9 +194,10 @@ int tvc_sac_sync_derived(tvc_sac* sac, void* stream);
 
 /* Policy part of get_action (agent/...:765-789) for n rows: mean/log_std (clamped to [-20,2]) and
  * action = clamp(mean + exp(log_std) * eps, -1, 1); eps_dev NULL = deterministic (action = clamp(mean)).
+ * flags bit 0: do not clamp (the safety layer sees the raw sample, agent/...:780-789).
  * obs_dev float[n,obs]; act_dev float[n,A]; mean_dev / logstd_dev float[n,A] or NULL. */
 int tvc_sac_act(tvc_sac* sac, const float* obs_dev, int32_t n, const float* eps_dev, float* act_dev, float* mean_dev,
-                float* logstd_dev, void* stream);
+                float* logstd_dev, int32_t flags, void* stream);
 
 /* One _update_sac (agent/...:950-1016) on a batch of batch_size rows, in four phases so that the caller can
  * all-reduce gradients between them (data parallel, K10):
@@ -225,6 +226,31 @@ int tvc_nn_linear_forward(const float* X, const float* W, const float* b, float*
 
 /* critic forward q1(s,a), q2(s,a) for n <= batch_size rows (tests / diagnostics): q_dev float[2,n] */
 int tvc_sac_q_values(tvc_sac* sac, const float* s, const float* a, int32_t n, int32_t use_target, float* q_dev, void* stream);
+
+/* ------------------------------------------------------------------ small MLPs of the acting path (K9, K12) */
+
+typedef struct tvc_mlp tvc_mlp;
+/* dims[0] -> dims[1] -> ... -> dims[n_layers], hidden activation act (1 GELU, 2 ReLU), last layer linear.
+ * Parameters: caller-owned flat fp32 device buffer, layer l at tvc_mlp_tensor_offset (weight [out,in] row-major,
+ * then bias), every tensor 16-byte aligned; tvc_mlp_param_count floats in total (host-only queries). */
+int64_t tvc_mlp_param_count(const int32_t* dims, int32_t n_layers);
+int tvc_mlp_tensor_offset(const int32_t* dims, int32_t n_layers, int32_t layer, int64_t* w_off, int64_t* b_off);
+int tvc_mlp_create(const int32_t* dims, int32_t n_layers, int32_t act, int32_t max_rows, int32_t device,
+                   const float* params_dev, tvc_mlp** out);
+void tvc_mlp_destroy(tvc_mlp* mlp);
+/* out[n, dims_last] = MLP([x[:, :k1] | x2[:, :dims0-k1]]); x row stride x_ld, x2 row stride x2_ld (x2 may be NULL
+ * when k1 == dims0). */
+int tvc_mlp_forward(tvc_mlp* mlp, const float* x, int32_t x_ld, int32_t k1, const float* x2, int32_t x2_ld, int32_t n,
+                    float* out, void* stream);
+/* CuriosityModule.compute_intrinsic_reward (env/enhanced_rocket_tvc_env.py:257-269) for n envs with the forward
+ * model in `mlp` (D+A -> ... -> D): rew[m] += 0.01 * mean((f([prev_obs[m,:D] | act[m]]) - obs[m,:D])^2) unless
+ * skip[m] != 0 (first step of an episode, env/...:496).  prev_obs / obs have row stride obs_ld. */
+int tvc_curiosity_add(tvc_mlp* mlp, const float* prev_obs, int32_t obs_ld, const float* act, int32_t act_dim,
+                      const float* obs, const uint8_t* skip, float* rew, int32_t n, void* stream);
+/* SafetyLayer.forward (agent/multi_algorithm_agent.py:304-351) followed by get_action's clamp (:789), with the
+ * correction net in `mlp` (state_dim+A -> ... -> A): out = clamp(violates ? net([state | proposed]) : proposed). */
+int tvc_safety_apply(tvc_mlp* mlp, const float* state, int32_t state_dim, const float* proposed, float* out, int32_t n,
+                     float max_tilt, float max_angular_velocity, float max_control_effort, void* stream);
 
 /* ------------------------------------------------------------------ replay buffer (K8) */
 

@@ -158,3 +158,29 @@ def mlp_critic_forward(Q, s, a):
     h = F.relu(torch.cat([s, a], -1) @ Q["0.weight"].T + Q["0.bias"])
     h = F.relu(h @ Q["2.weight"].T + Q["2.bias"])
     return (h @ Q["4.weight"].T + Q["4.bias"]).squeeze(-1)
+
+
+# --- acting-path extras of the reference (both nets are created with random weights and never trained there)
+def curiosity_reward(F_, prev_obs8, action, obs8):
+    """CuriosityModule.compute_intrinsic_reward, env/enhanced_rocket_tvc_env.py:257-269, batched over rows:
+    0.01 * mean((forward_model([prev_obs8 | action]) - obs8)^2).  F_: forward_model state_dict ('0','2','4')."""
+    x = torch.cat([prev_obs8, action], -1)
+    h = F.relu(x @ F_["0.weight"].T + F_["0.bias"])
+    h = F.relu(h @ F_["2.weight"].T + F_["2.bias"])
+    pred = h @ F_["4.weight"].T + F_["4.bias"]
+    return 0.01 * ((pred - obs8) ** 2).mean(-1)
+
+
+def safety_layer(S, state, proposed, max_tilt=0.52, max_w=5.0, max_effort=1.0):
+    """SafetyLayer.forward (agent/multi_algorithm_agent.py:304-351) followed by get_action's clamp (:789)."""
+    q, w = state[:, :4], state[:, 4:7]
+    pitch = torch.asin(2 * (q[:, 3] * q[:, 1] - q[:, 2] * q[:, 0]))
+    yaw = torch.atan2(2 * (q[:, 3] * q[:, 2] + q[:, 0] * q[:, 1]), 1 - 2 * (q[:, 1] ** 2 + q[:, 2] ** 2))
+    tilt = torch.sqrt(pitch ** 2 + yaw ** 2)
+    viol = (tilt > max_tilt) | (w.norm(dim=1) > max_w) | (proposed.norm(dim=1) > max_effort)
+    x = torch.cat([state, proposed], -1)
+    h = F.relu(x @ S["0.weight"].T + S["0.bias"])
+    h = F.relu(h @ S["2.weight"].T + S["2.bias"])
+    corr = h @ S["4.weight"].T + S["4.bias"]
+    out = torch.where(viol.unsqueeze(1), corr, proposed)
+    return torch.clamp(out, -1.0, 1.0), viol

@@ -1,0 +1,50 @@
+"""Curiosity bonus and safety layer on the device vs the reference's own outputs (tests/golden/aux_ref.npz) and the
+torch restatement.  fp32; tolerances: curiosity 2e-5 rel, safety 5e-6 abs on non-ambiguous rows."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sac_torch as st
+from tests.test_aux_oracle_golden import aux_setup
+
+pytestmark = pytest.mark.gpu
+
+
+def test_curiosity_matches_reference_golden():
+    from tvc_ai_amd.curiosity import VecCuriosity
+    g, Fm, (cs, ca, cs2), _, _ = aux_setup()
+    cur = VecCuriosity(max_rows=512)
+    cur.load_state_dict(Fm)
+    prev = torch.from_numpy(cs).cuda()          # full 10-wide obs rows: the kernel reads the first 8 columns
+    nxt = torch.from_numpy(cs2).cuda()
+    act = torch.from_numpy(np.clip(ca, -1, 1)).cuda()
+    r = cur.intrinsic_reward(prev, act, nxt)
+    np.testing.assert_allclose(r[:64].cpu().numpy(), g["cur_reward"], rtol=2e-5, atol=1e-8)
+    ref = st.curiosity_reward(Fm, torch.from_numpy(cs[:, :8]), torch.from_numpy(np.clip(ca, -1, 1)), torch.from_numpy(cs2[:, :8]))
+    np.testing.assert_allclose(r.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=1e-8)
+    # skip mask + in-place accumulate
+    rew = torch.full((256,), 5.0).cuda()
+    skip = (torch.arange(256) % 3 == 0).to(torch.uint8).cuda()
+    cur.add_intrinsic_reward(prev, act, nxt, rew, skip)
+    exp = 5.0 + np.where(np.arange(256) % 3 == 0, 0.0, ref.numpy())
+    np.testing.assert_allclose(rew.cpu().numpy(), exp, rtol=1e-5)
+    cur.close()
+
+
+def test_safety_layer_matches_reference_golden():
+    from tvc_ai_amd.curiosity import SafetyLayer
+    g, _, _, Sm, (ss, sa, _) = aux_setup()
+    sl = SafetyLayer(max_rows=512)
+    sl.load_state_dict(Sm)
+    out = sl.apply(torch.from_numpy(ss).cuda(), torch.from_numpy(sa).cuda()).cpu().numpy()
+    np.testing.assert_allclose(out, g["safety_out"], atol=5e-6)
+    sl.close()
+
+
+def test_agent_get_action_with_safety_layer_enabled():
+    from tvc_ai_amd.agent import MultiAlgorithmAgent
+    cfg = {"tvc_native": {"batch_size": 1, "max_act_rows": 64}, "safety": {"safety_layer": {"enabled": True}}}
+    agent = MultiAlgorithmAgent(10, 2, cfg)
+    obs = torch.randn(32, 10)
+    a, info = agent.get_action(obs)
+    assert a.shape == (32, 2) and np.all(np.abs(a) <= 1.0) and info["algorithm"] == "sac"

@@ -78,7 +78,14 @@ SIGNATURES.update({
     "tvc_sac_create": (C.c_int, [C.POINTER(SacCfg), C.c_int32, _VP, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "tvc_sac_destroy": (None, [_VP]),
     "tvc_sac_sync_derived": (C.c_int, [_VP, _VP]),
-    "tvc_sac_act": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, _VP]),
+    "tvc_sac_act": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, C.c_int32, _VP]),
+    "tvc_mlp_param_count": (C.c_int64, [C.POINTER(C.c_int32), C.c_int32]),
+    "tvc_mlp_tensor_offset": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "tvc_mlp_create": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, C.POINTER(_VP)]),
+    "tvc_mlp_destroy": (None, [_VP]),
+    "tvc_mlp_forward": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, _VP, C.c_int32, C.c_int32, _VP, _VP]),
+    "tvc_curiosity_add": (C.c_int, [_VP, _VP, C.c_int32, _VP, C.c_int32, _VP, _VP, _VP, C.c_int32, _VP]),
+    "tvc_safety_apply": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, C.c_int32, C.c_float, C.c_float, C.c_float, _VP]),
     "tvc_sac_critic_grads": (C.c_int, [_VP] + [_VP] * 8),
     "tvc_sac_critic_apply": (C.c_int, [_VP, C.c_float, _VP]),
     "tvc_sac_actor_grads": (C.c_int, [_VP, _VP, _VP, _VP, _VP]),

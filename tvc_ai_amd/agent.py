@@ -227,15 +227,15 @@ class NativeSAC:
         return {n[len(pre):]: self.view(n).cpu().clone() for n, _, _, _ in self.table if n.startswith(pre)}
 
     # -- hot path
-    def act(self, obs: torch.Tensor, eps: Optional[torch.Tensor] = None, out=None):
-        """-> (action[n,A] clamped to [-1,1], mean, log_std); eps None = deterministic."""
+    def act(self, obs: torch.Tensor, eps: Optional[torch.Tensor] = None, out=None, clamp: bool = True):
+        """-> (action[n,A] clamped to [-1,1] unless clamp=False, mean, log_std); eps None = deterministic."""
         n, A = obs.shape[0], self.cfg.act_dim
         assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.cfg.obs_dim
         if out is None:
             out = tuple(torch.empty((n, A), dtype=torch.float32, device=self.device) for _ in range(3))
         act, mean, ls = out
         nat.check(self.L.tvc_sac_act(self._h, obs.data_ptr(), n, nat.ptr(eps), act.data_ptr(), mean.data_ptr(), ls.data_ptr(),
-                                     self._stream()))
+                                     0 if clamp else 1, self._stream()))
         return act, mean, ls
 
     def update(self, s, a, r, s2, d, eps_next, eps_new, all_reduce=None, grad_scale: float = 1.0):
@@ -346,6 +346,15 @@ class MultiAlgorithmAgent:
         self.selection_strategy = (self.config.get("algorithms", {}).get("ensemble", {}) or {}).get("selection_strategy", "dynamic")
         self._gen = torch.Generator(device=self.device).manual_seed(seed)
         self._current_algorithm = "sac"
+        # SafetyLayer (agent/...:515-520): an untrained correction net + constraint test, applied when enabled
+        self.safety_layer = None
+        saf = self.config.get("safety", {}) or {}
+        if (saf.get("safety_layer", {}) or {}).get("enabled", False):
+            from .curiosity import SafetyLayer
+            cons = (saf.get("constrained_rl", {}) or {}).get("constraints", {}) or {}
+            self.safety_layer = SafetyLayer(device=self.device, max_rows=int(native.get("max_act_rows", 4096)),
+                                            state_dim=obs_dim, action_dim=action_dim, max_tilt=cons.get("max_tilt", 0.52),
+                                            max_angular_velocity=cons.get("max_angular_velocity", 5.0), seed=seed)
 
     def to(self, device):
         if torch.device(device) != self.device:
@@ -364,7 +373,9 @@ class MultiAlgorithmAgent:
                 state = state.unsqueeze(0)
             state = state.contiguous()
             eps = None if deterministic else torch.randn((state.shape[0], self.action_dim), device=self.device, generator=self._gen)
-            act, mean, ls = self.sac.act(state, eps)
+            act, mean, ls = self.sac.act(state, eps, clamp=self.safety_layer is None)
+            if self.safety_layer is not None:  # sees the raw sample, then the result is clamped (agent/...:785-789)
+                act = self.safety_layer.apply(state, act)
             info = {"algorithm": "sac", "mean": mean.cpu().numpy(), "log_std": ls.cpu().numpy(), "value": None}
             return act.cpu().numpy(), info
         except Exception as e:  # reference convention: log and fall back to a random action (agent/...:804-809)

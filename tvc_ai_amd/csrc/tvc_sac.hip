@@ -672,7 +672,8 @@ void tvc_sac_destroy(tvc_sac* h) {
     delete h;
 }
 
-int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float* act, float* mean, float* logstd, void* stream) {
+int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float* act, float* mean, float* logstd, int32_t flags,
+                void* stream) {
     if (!h || !obs || !act) return tvc::set_error(TVC_EINVAL, "null argument");
     if (n < 1 || n > h->cfg.max_act_rows) return tvc::set_error(TVC_EINVAL, "n=%d outside [1, max_act_rows=%d]", n, h->cfg.max_act_rows);
     TVC_HIP_CHECK(hipSetDevice(h->device));
@@ -683,7 +684,8 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
     net_forward(h->actor_inf, h->P_actor(), 0, obs, 0, n, 1, h->ictx, false, h->cfg.family == 0 ? h->pe : nullptr, h->cfg.pe_rows, st,
                 h->ov);
     const float* head = h->ictx.Y.back();
-    hipLaunchKernelGGL(sample_action_kernel, dim3((n * A + 255) / 256), dim3(256), 0, st, head, eps, act, mean, logstd, n, A, 1);
+    hipLaunchKernelGGL(sample_action_kernel, dim3((n * A + 255) / 256), dim3(256), 0, st, head, eps, act, mean, logstd, n, A,
+                       (flags & 1) ? 0 : 1);
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -834,6 +836,191 @@ int tvc_sac_q_values(tvc_sac* h, const float* s, const float* a, int32_t n, int3
     hipLaunchKernelGGL(concat_kernel, dim3((n * (no + A) + 255) / 256), dim3(256), 0, st, s, a, h->xcat, n, no, A);
     net_forward(h->critic, use_target ? h->P_tq() : h->P_q(), h->n_critic, h->xcat, 0, n, 2, h->cctx, false, nullptr, 0, st);
     TVC_HIP_CHECK(hipMemcpyAsync(q, h->cctx.Y.back(), 2L * n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ small MLP handle + curiosity / safety kernels (K9, K12)
+struct tvc_mlp {
+    NetDef net;
+    Ctx ctx;
+    const float* params;
+    void* slab;
+    float* xcat;
+    float* tmp;
+    int device, max_rows, in_dim, out_dim;
+};
+
+namespace {
+static NetDef build_mlp(const int32_t* dims, int n_layers, int act) {
+    NetDef n;
+    n.in_dim = dims[0];
+    int x = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const bool last = l == n_layers - 1;
+        const std::string name = std::to_string(2 * l);  // nn.Sequential numbering: Linear, act, Linear, ...
+        if (last && dims[l + 1] <= 4 && (dims[l] % 4) == 0) x = n.add(OP_HEAD, name, dims[l], dims[l + 1], 0, x, -1, 0);
+        else x = n.add(OP_LINEAR, name, dims[l], dims[l + 1], last ? ACT_NONE : act, x, -1, 0);
+    }
+    n.finish();
+    return n;
+}
+static int mlp_dims_ok(const int32_t* dims, int n_layers) {
+    if (!dims || n_layers < 1 || n_layers > 8) return tvc::set_error(TVC_EINVAL, "bad dims / n_layers");
+    for (int l = 0; l <= n_layers; ++l)
+        if (dims[l] < 1 || dims[l] > 4096) return tvc::set_error(TVC_EINVAL, "layer width out of range");
+    return 0;
+}
+
+// dense [n, k1 + k2] input from the first k1 columns of a (row stride lda) and the first k2 of b (row stride ldb)
+__global__ void gather2_kernel(const float* __restrict__ a, int lda, int k1, const float* __restrict__ b, int ldb, int k2,
+                               float* __restrict__ o, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = k1 + k2;
+    if (i >= n * K) return;
+    const int m = i / K, k = i - m * K;
+    o[i] = k < k1 ? a[(long)m * lda + k] : b[(long)m * ldb + (k - k1)];
+}
+
+// CuriosityModule.compute_intrinsic_reward (env/enhanced_rocket_tvc_env.py:257-269): rew += 0.01 * mean((pred - obs[:D])^2),
+// skipped where skip[m] != 0 (first step of an episode, ref :496)
+__global__ void curiosity_reward_kernel(const float* __restrict__ pred, const float* __restrict__ obs, int obs_ld,
+                                        const unsigned char* __restrict__ skip, float* __restrict__ rew, int M, int D) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    if (skip && skip[m]) return;
+    float e = 0.f;
+    for (int j = 0; j < D; ++j) {
+        const float d = pred[(long)m * D + j] - obs[(long)m * obs_ld + j];
+        e += d * d;
+    }
+    rew[m] += 0.01f * e / (float)D;
+}
+
+// SafetyLayer.forward (agent/multi_algorithm_agent.py:304-351) + the clamp of get_action (:789)
+__global__ void safety_select_kernel(const float* __restrict__ state, int sd, const float* __restrict__ proposed,
+                                     const float* __restrict__ corr, float* __restrict__ out, int M, int A, float max_tilt,
+                                     float max_w, float max_effort) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float* q = state + (long)m * sd;
+    const float pitch = asinf(2.0f * (q[3] * q[1] - q[2] * q[0]));
+    const float yaw = atan2f(2.0f * (q[3] * q[2] + q[0] * q[1]), 1.0f - 2.0f * (q[1] * q[1] + q[2] * q[2]));
+    const float tilt = sqrtf(pitch * pitch + yaw * yaw);
+    const float wn = sqrtf(q[4] * q[4] + q[5] * q[5] + q[6] * q[6]);
+    float an = 0.f;
+    for (int j = 0; j < A; ++j) an += proposed[(long)m * A + j] * proposed[(long)m * A + j];
+    const bool viol = (tilt > max_tilt) || (wn > max_w) || (sqrtf(an) > max_effort);
+    for (int j = 0; j < A; ++j) {
+        const float v = viol ? corr[(long)m * A + j] : proposed[(long)m * A + j];
+        out[(long)m * A + j] = fminf(fmaxf(v, -1.0f), 1.0f);
+    }
+}
+
+// runs the MLP on [a[:, :k1] | b[:, :k2]]; returns the device pointer of the [n, out_dim] result (inside the handle)
+static const float* mlp_run(tvc_mlp* h, const float* a, int lda, int k1, const float* b, int ldb, int n, hipStream_t st) {
+    const int k2 = h->in_dim - k1;
+    const float* in = a;
+    if (k2 > 0 || lda != h->in_dim) {
+        hipLaunchKernelGGL(gather2_kernel, dim3((n * h->in_dim + 255) / 256), dim3(256), 0, st, a, lda, k1, b, ldb, k2, h->xcat, n);
+        in = h->xcat;
+    }
+    for (size_t i = 1; i < h->ctx.gY.size(); ++i) h->ctx.gY[i] = (long)n * h->net.buf_dim[i];
+    net_forward(h->net, h->params, 0, in, 0, n, 1, h->ctx, false, nullptr, 0, st);
+    return h->ctx.Y.back();
+}
+}  // namespace
+
+extern "C" {
+
+int64_t tvc_mlp_param_count(const int32_t* dims, int32_t n_layers) {
+    if (mlp_dims_ok(dims, n_layers)) return -1;
+    return build_mlp(dims, n_layers, ACT_RELU).n_params;
+}
+int tvc_mlp_tensor_offset(const int32_t* dims, int32_t n_layers, int32_t layer, int64_t* w_off, int64_t* b_off) {
+    if (int e = mlp_dims_ok(dims, n_layers)) return e;
+    if (layer < 0 || layer >= n_layers) return tvc::set_error(TVC_EINVAL, "layer out of range");
+    NetDef n = build_mlp(dims, n_layers, ACT_RELU);
+    if (w_off) *w_off = n.ops[layer].w;
+    if (b_off) *b_off = n.ops[layer].b;
+    return 0;
+}
+int tvc_mlp_create(const int32_t* dims, int32_t n_layers, int32_t act, int32_t max_rows, int32_t device, const float* params_dev,
+                   tvc_mlp** out) {
+    if (!out) return tvc::set_error(TVC_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (int e = mlp_dims_ok(dims, n_layers)) return e;
+    if (!params_dev || max_rows < 1 || act < ACT_NONE || act > ACT_RELU) return tvc::set_error(TVC_EINVAL, "bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return tvc::set_error(TVC_ENODEV, "no HIP device visible: libtvc_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return tvc::set_error(TVC_EINVAL, "device out of range");
+    TVC_HIP_CHECK(hipSetDevice(device));
+    tvc_mlp* h = new (std::nothrow) tvc_mlp();
+    if (!h) return tvc::set_error(TVC_ENOMEM, "host allocation failed");
+    h->net = build_mlp(dims, n_layers, act);
+    h->params = params_dev; h->device = device; h->max_rows = max_rows; h->in_dim = dims[0]; h->out_dim = dims[n_layers];
+    int maxd = dims[0];
+    for (int l = 1; l <= n_layers; ++l) maxd = std::max(maxd, (int)dims[l]);
+    const long bytes = 8L * (((long)max_rows * maxd * 4 + 255) & ~255L) + 4096;
+    hipError_t he = hipMalloc(&h->slab, bytes);
+    if (he != hipSuccess) {
+        delete h;
+        return tvc::set_error(TVC_ENOMEM, "hipMalloc(%ld) failed: %s", bytes, hipGetErrorString(he));
+    }
+    char* p = (char*)h->slab;
+    h->xcat = (float*)carve(p, (long)max_rows * maxd * 4);
+    h->tmp = (float*)carve(p, (long)max_rows * maxd * 4);
+    if (ctx_alloc_infer(h->ctx, h->net, max_rows, p) != 0) {
+        (void)hipFree(h->slab);
+        delete h;
+        return tvc::set_error(TVC_EINVAL, "slot allocation failed");
+    }
+    *out = h;
+    return 0;
+}
+void tvc_mlp_destroy(tvc_mlp* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipFree(h->slab);
+    delete h;
+}
+int tvc_mlp_forward(tvc_mlp* h, const float* x, int32_t x_ld, int32_t k1, const float* x2, int32_t x2_ld, int32_t n, float* out,
+                    void* stream) {
+    if (!h || !x || !out) return tvc::set_error(TVC_EINVAL, "null argument");
+    if (n < 1 || n > h->max_rows || k1 < 1 || k1 > h->in_dim || (k1 < h->in_dim && !x2)) return tvc::set_error(TVC_EINVAL, "bad n / k1");
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const float* y = mlp_run(h, x, x_ld, k1, x2, x2_ld, n, st);
+    TVC_HIP_CHECK(hipMemcpyAsync(out, y, (long)n * h->out_dim * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+// rew[m] += 0.01 * mean((f([prev_obs[m, :D] | act[m]]) - obs[m, :D])^2) unless skip[m]   (env/...:496-502)
+int tvc_curiosity_add(tvc_mlp* h, const float* prev_obs, int32_t obs_ld, const float* act, int32_t act_dim, const float* obs,
+                      const uint8_t* skip, float* rew, int32_t n, void* stream) {
+    if (!h || !prev_obs || !act || !obs || !rew) return tvc::set_error(TVC_EINVAL, "null argument");
+    const int D = h->out_dim;
+    if (n < 1 || n > h->max_rows || D + act_dim != h->in_dim || D > obs_ld) return tvc::set_error(TVC_EINVAL, "shape mismatch");
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const float* pred = mlp_run(h, prev_obs, obs_ld, D, act, act_dim, n, st);
+    hipLaunchKernelGGL(curiosity_reward_kernel, dim3((n + 255) / 256), dim3(256), 0, st, pred, obs, obs_ld, skip, rew, n, D);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+// out = clamp(violates(state, proposed) ? safety_net([state | proposed]) : proposed, -1, 1)   (agent/...:304-351, :789)
+int tvc_safety_apply(tvc_mlp* h, const float* state, int32_t state_dim, const float* proposed, float* out, int32_t n, float max_tilt,
+                     float max_w, float max_effort, void* stream) {
+    if (!h || !state || !proposed || !out) return tvc::set_error(TVC_EINVAL, "null argument");
+    const int A = h->out_dim;
+    if (n < 1 || n > h->max_rows || state_dim + A != h->in_dim || state_dim < 7) return tvc::set_error(TVC_EINVAL, "shape mismatch");
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const float* corr = mlp_run(h, state, state_dim, state_dim, proposed, A, n, st);
+    hipLaunchKernelGGL(safety_select_kernel, dim3((n + 255) / 256), dim3(256), 0, st, state, state_dim, proposed, corr, out, n, A,
+                       max_tilt, max_w, max_effort);
+    TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }
 

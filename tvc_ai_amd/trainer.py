@@ -18,7 +18,7 @@ from .parallel import GradSync, broadcast_parameters
 class VecTrainer:
     def __init__(self, num_envs: int, device="cuda:0", config: Optional[dict] = None, family: int = 0, batch_size: int = 256,
                  replay_capacity: int = 1_000_000, seed: int = 42, rank: int = 0, world: int = 1, updates_per_step: int = 1,
-                 max_episode_steps: int = 1000, **env_over):
+                 max_episode_steps: int = 1000, enable_curiosity: bool = False, **env_over):
         self.device = torch.device(device)
         self.n, self.B, self.world, self.rank = num_envs, batch_size, world, rank
         self.updates_per_step = updates_per_step
@@ -29,6 +29,11 @@ class VecTrainer:
         self.sac.sync_derived()
         self.rb = ReplayBuffer(replay_capacity, 10, 2, device=self.device, seed=seed * 1000003 + rank)
         self.sync = GradSync() if world > 1 else None
+        # intrinsic curiosity bonus of the reference's training env (scripts/train.py:318, env/...:496-502)
+        self.curiosity = None
+        if enable_curiosity:
+            from .curiosity import VecCuriosity
+            self.curiosity = VecCuriosity(device=self.device, max_rows=num_envs, seed=seed)
         d, n, B = self.device, num_envs, batch_size
         self.obs = [torch.empty((n, 10), device=d), torch.empty((n, 10), device=d)]
         self.cur = 0
@@ -40,6 +45,7 @@ class VecTrainer:
         self.eps2 = torch.empty((B, 2), device=d)
         self.batch = (torch.empty((B, 10), device=d), torch.empty((B, 2), device=d), torch.empty((B,), device=d),
                       torch.empty((B, 10), device=d), torch.empty((B,), device=d))
+        self.prev_done = torch.ones((n,), dtype=torch.uint8, device=d)  # 1 = next step is the first of an episode
         torch.manual_seed(seed + rank)  # default CUDA generator: hipGraph-capturable normal draws
         o, _ = self.env.reset()
         self.obs[0].copy_(o)
@@ -49,6 +55,8 @@ class VecTrainer:
         self.env.close()
         self.sac.close()
         self.rb.close()
+        if self.curiosity is not None:
+            self.curiosity.close()
 
     def collect(self):
         """act + env step + replay insert"""
@@ -56,6 +64,9 @@ class VecTrainer:
         self.eps_act.normal_()
         self.sac.act(cur, self.eps_act, out=(self.act, self.mean, self.ls))
         o, rew, term, trunc, info = self.env.step(self.act, out_obs=nxt)
+        if self.curiosity is not None:  # added after the env's clip, skipped on the first step of an episode
+            self.curiosity.add_intrinsic_reward(cur, self.act, info["final_observation"], rew, self.prev_done)
+            torch.bitwise_or(term, trunc, out=self.prev_done)
         self.rb.insert(cur, self.act, rew, info["final_observation"], term, trunc)
         self.cur = 1 - self.cur
 
@@ -93,7 +104,7 @@ def bench_train(args, world, rank, device):
 
 def smoke():
     """tiny end-to-end train loop on cuda:0 (called from __graft_entry__.smoke)"""
-    tr = VecTrainer(256, device="cuda:0", family=0, batch_size=64, replay_capacity=4096, seed=1)
+    tr = VecTrainer(256, device="cuda:0", family=0, batch_size=64, replay_capacity=4096, seed=1, enable_curiosity=True)
     for _ in range(6):
         tr.step(True)
     torch.cuda.synchronize()
