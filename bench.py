@@ -43,6 +43,7 @@ def parse():
                          "8192 = the per-GPU shard of configs[4] (65 536 envs on 8 GPUs)")
     ap.add_argument("--workload", choices=["physics", "train", "auto"], default="auto")
     ap.add_argument("--family", type=int, default=0, help="SAC network family: 0 = reference shapes, 1 = 256x256 MLP")
+    ap.add_argument("--no-overlap", action="store_true", help="train: run the update after the acting pass instead of beside it")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per K steps")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample length (0 = skip)")
     ap.add_argument("--roofline-envs", type=int, default=1 << 22, help="bandwidth-regime size for the extra roofline point")

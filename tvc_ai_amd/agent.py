@@ -255,6 +255,20 @@ class NativeSAC:
         nat.check(L.tvc_sac_actor_apply(h, grad_scale, st))
         return self.losses
 
+    # the four phases of update(), for callers that interleave them with other work / collectives
+    def critic_grads(self, s, a, r, s2, d, eps_next):
+        nat.check(self.L.tvc_sac_critic_grads(self._h, s.data_ptr(), a.data_ptr(), r.data_ptr(), s2.data_ptr(), d.data_ptr(),
+                                              eps_next.data_ptr(), self.losses.data_ptr(), self._stream()))
+
+    def critic_apply(self, grad_scale: float = 1.0):
+        nat.check(self.L.tvc_sac_critic_apply(self._h, grad_scale, self._stream()))
+
+    def actor_grads(self, s, eps_new):
+        nat.check(self.L.tvc_sac_actor_grads(self._h, s.data_ptr(), eps_new.data_ptr(), self.losses.data_ptr(), self._stream()))
+
+    def actor_apply(self, grad_scale: float = 1.0):
+        nat.check(self.L.tvc_sac_actor_apply(self._h, grad_scale, self._stream()))
+
     def q_values(self, s, a, target=False):
         q = torch.empty((2, s.shape[0]), dtype=torch.float32, device=self.device)
         nat.check(self.L.tvc_sac_q_values(self._h, s.data_ptr(), a.data_ptr(), s.shape[0], 1 if target else 0, q.data_ptr(),

@@ -18,7 +18,7 @@ from .parallel import GradSync, broadcast_parameters
 class VecTrainer:
     def __init__(self, num_envs: int, device="cuda:0", config: Optional[dict] = None, family: int = 0, batch_size: int = 256,
                  replay_capacity: int = 1_000_000, seed: int = 42, rank: int = 0, world: int = 1, updates_per_step: int = 1,
-                 max_episode_steps: int = 1000, enable_curiosity: bool = False, **env_over):
+                 max_episode_steps: int = 1000, enable_curiosity: bool = False, overlap: bool = True, **env_over):
         self.device = torch.device(device)
         self.n, self.B, self.world, self.rank = num_envs, batch_size, world, rank
         self.updates_per_step = updates_per_step
@@ -29,6 +29,8 @@ class VecTrainer:
         self.sac.sync_derived()
         self.rb = ReplayBuffer(replay_capacity, 10, 2, device=self.device, seed=seed * 1000003 + rank)
         self.sync = GradSync() if world > 1 else None
+        self.overlap = overlap
+        self._side = torch.cuda.Stream(self.device)
         # intrinsic curiosity bonus of the reference's training env (scripts/train.py:318, env/...:496-502)
         self.curiosity = None
         if enable_curiosity:
@@ -79,11 +81,39 @@ class VecTrainer:
         return self.sac.update(s, a, r, s2, d, self.eps1, self.eps2, all_reduce=self.sync, grad_scale=gs)
 
     def step(self, learn: bool = True):
-        self.collect()
-        if learn:
-            for _ in range(self.updates_per_step):
-                self.learn()
+        if learn and self.overlap and self.steps > 0 and self.updates_per_step == 1:
+            self._step_overlapped()
+        else:
+            self.collect()
+            if learn:
+                for _ in range(self.updates_per_step):
+                    self.learn()
         self.steps += 1
+
+    def _step_overlapped(self):
+        """Same work as collect() + learn(), on two HIP streams: the update's gradient phases (hundreds of
+        latency-bound batch-256 kernels, plus the RCCL all-reduces when data parallel) run beside the acting pass
+        (large GEMMs over all envs).  Only the actor's Adam step waits for both, because acting reads the policy
+        parameters.  The batch is drawn before this step's transitions are inserted."""
+        main = torch.cuda.current_stream(self.device)
+        sac, side = self.sac, self._side
+        self.rb.sample(self.B, out=self.batch)
+        self.eps1.normal_()
+        self.eps2.normal_()
+        s, a, r, s2, d = self.batch
+        gs = self.sync.grad_scale if self.sync is not None else 1.0
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            sac.critic_grads(s, a, r, s2, d, self.eps1)
+            if self.sync is not None:
+                self.sync(sac.grads[sac.n_policy:])
+            sac.critic_apply(gs)
+            sac.actor_grads(s, self.eps2)
+            if self.sync is not None:
+                self.sync(sac.grads[:sac.n_policy])
+        self.collect()
+        main.wait_stream(side)
+        sac.actor_apply(gs)
 
     def stats(self):
         return {"env_steps": self.steps * self.n, "updates": self.steps * self.updates_per_step,
@@ -94,7 +124,7 @@ def bench_train(args, world, rank, device):
     """bench.py workload 'train': returns the step function and the env (for the roofline leg)."""
     family = getattr(args, "family", 0)
     tr = VecTrainer(args.envs_per_gpu, device=device, family=family, batch_size=256, replay_capacity=1_000_000, seed=42,
-                    rank=rank, world=world, updates_per_step=1)
+                    rank=rank, world=world, updates_per_step=1, overlap=not getattr(args, "no_overlap", False))
     fam = "reference shapes (seq-len-1 transformer actor 2.26M trainable params, 512/256 GELU+LN critics)" if family == 0 \
         else "256x256 ReLU MLP actor/critics"
     return {"step_fn": lambda k: tr.step(True), "env": tr.env, "trainer": tr,
