@@ -54,11 +54,19 @@ def dist_setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal hooks for a 1-GPU box: TVC_FORCE_DEVICE=0 puts every rank on one card, TVC_DIST_BACKEND=gloo swaps
+    # RCCL (which refuses two ranks per GPU) for gloo; the launch contract (nccl, one rank per GPU) is the default
+    if os.environ.get("TVC_FORCE_DEVICE") is not None:
+        local = int(os.environ["TVC_FORCE_DEVICE"])
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("TVC_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
         local = 0
@@ -263,9 +271,15 @@ def main():
     out.update(extra)
 
     if rank == 0:
-        out.update(roofline_report(args, workload, n, step_fn if workload == "physics" else None, dev_us_per_step, device))
+        try:
+            out.update(roofline_report(args, workload, n, step_fn if workload == "physics" else None, dev_us_per_step, device))
+        except Exception as e:  # the headline line must survive a failure of the diagnostic legs
+            out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
         if args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     barrier(world)
     if world > 1:

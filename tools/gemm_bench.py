@@ -5,7 +5,7 @@ import torch
 from tvc_ai_amd import _native as nat
 L = nat.load()
 st = lambda: torch.cuda.current_stream().cuda_stream
-shapes = [(65536, 256, 256), (65536, 512, 256), (65536, 256, 512), (8192, 256, 256), (8192, 512, 256), (256, 256, 256), (256, 512, 256), (256, 256, 512)]
+shapes = [(65536, 256, 256), (65536, 512, 256), (65536, 256, 512), (65536, 512, 512), (8192, 256, 256), (8192, 512, 256), (256, 256, 256), (256, 512, 256), (256, 256, 512)]
 for (M, N, K) in shapes:
     X = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda")
     Y = torch.empty(M, N, device="cuda")

@@ -138,15 +138,17 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
             a4[i] = *reinterpret_cast<const float4*>(&As[wr * 32 + i * 16 + (lane & 15)][(lane >> 4) * 4]);
             b4[i] = *reinterpret_cast<const float4*>(&Bs[wc * 32 + i * 16 + (lane & 15)][(lane >> 4) * 4]);
         }
+        // k-component outermost: consecutive MFMAs go to different accumulators (16x16x4 f32 issues every 32 cycles
+        // but needs 40 between dependent ones)
+        const float av[2][4] = {{a4[0].x, a4[0].y, a4[0].z, a4[0].w}, {a4[1].x, a4[1].y, a4[1].z, a4[1].w}};
+        const float bv[2][4] = {{b4[0].x, b4[0].y, b4[0].z, b4[0].w}, {b4[1].x, b4[1].y, b4[1].z, b4[1].w}};
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
-            }
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][c], bv[j][c], acc[i][j], 0, 0, 0);
     }
     // epilogue.  C/D map of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
     float* C = g.C + z * g.gC;
