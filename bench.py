@@ -43,6 +43,7 @@ def parse():
                          "8192 = the per-GPU shard of configs[4] (65 536 envs on 8 GPUs)")
     ap.add_argument("--workload", choices=["physics", "train", "auto"], default="auto")
     ap.add_argument("--family", type=int, default=0, help="SAC network family: 0 = reference shapes, 1 = 256x256 MLP")
+    ap.add_argument("--dr-stage", type=int, default=None, help="train: domain randomisation at curriculum stage 0-5 (default: off)")
     ap.add_argument("--no-overlap", action="store_true", help="train: run the update after the acting pass instead of beside it")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per K steps")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample length (0 = skip)")
@@ -362,6 +363,22 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
                            "launch_us": us, "flops_per_launch": 2.0 * M * N * K, "dtype": "f32 in / f32 acc MFMA"}
         del X, W, b, Y
         rep["roofline_integrator"] = integrator_roofline(n, device)
+        # learner alone (no env stepping): back-to-back SAC updates at B = 256 on a fixed batch
+        try:
+            from tvc_ai_amd.agent import NativeSAC, sac_cfg
+            sac = NativeSAC(sac_cfg(args.family, batch_size=256, max_act_rows=256), device=device, seed=1)
+            B = 256
+            bt = (torch.randn(B, 10, device=device), torch.rand(B, 2, device=device) * 2 - 1, torch.randn(B, device=device),
+                  torch.randn(B, 10, device=device), torch.zeros(B, device=device), torch.randn(B, 2, device=device),
+                  torch.randn(B, 2, device=device))
+            us_up = graph_time_us(lambda k: sac.update(*bt), 20, device)
+            flops = 4.88e9 if args.family == 0 else 0.565e9  # SURVEY 8d algorithmic minimum per update
+            rep["sac_learner_only"] = {"updates_per_s": 1e6 / us_up, "us_per_update": us_up, "batch": B,
+                                       "mfma_tflops": flops / (us_up * 1e-6) / 1e12,
+                                       "note": "latency-bound at batch 256 (H5): ~230 dependent launches per update"}
+            sac.close()
+        except Exception as e:
+            rep["sac_learner_only"] = {"error": str(e)}
     try:  # the integrator in its bandwidth regime (H3: small batches are launch/latency-bound)
         rep["roofline_integrator_large_n"] = integrator_roofline(args.roofline_envs, device)
     except Exception as e:  # never lose the headline line to the optional point

@@ -123,13 +123,20 @@ class VecTrainer:
 def bench_train(args, world, rank, device):
     """bench.py workload 'train': returns the step function and the env (for the roofline leg)."""
     family = getattr(args, "family", 0)
+    env_over = {}
+    stage = getattr(args, "dr_stage", None)
+    if stage is not None:  # BASELINE configs[4]: full domain randomisation at a curriculum stage (config.yaml:236-286, 340-349)
+        from .env import dr_from_yaml
+        env_over = dr_from_yaml({}, stage)
     tr = VecTrainer(args.envs_per_gpu, device=device, family=family, batch_size=256, replay_capacity=1_000_000, seed=42,
-                    rank=rank, world=world, updates_per_step=1, overlap=not getattr(args, "no_overlap", False))
+                    rank=rank, world=world, updates_per_step=1, overlap=not getattr(args, "no_overlap", False), **env_over)
     fam = "reference shapes (seq-len-1 transformer actor 2.26M trainable params, 512/256 GELU+LN critics)" if family == 0 \
         else "256x256 ReLU MLP actor/critics"
     return {"step_fn": lambda k: tr.step(True), "env": tr.env, "trainer": tr,
             "extra": {"updates_per_step": 1.0, "sac": {"family": fam, "batch": 256, "replay_capacity": 1_000_000,
-                                                      "utd": "1 update per vector step", "dtype": "f32 MFMA"}}}
+                                                      "utd": "1 update per vector step", "dtype": "f32 MFMA",
+                                                      "domain_randomisation": "off (shipped env)" if stage is None
+                                                      else f"curriculum stage {stage}: {env_over}"}}}
 
 
 def smoke():
