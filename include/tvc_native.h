@@ -140,6 +140,10 @@ int tvc_env_info(tvc_env* env, float* info_dev, void* stream);
  * reference, env/...:530-533): number of decrements until empty / until < 0.8 / until <= 0.1. */
 int tvc_env_fuel_thresholds(const tvc_env* env, int32_t* k_empty, int32_t* k_coast, int32_t* k_low);
 
+/* Philox4x32-10 (Random123) of n (counter[4], key[2]) pairs on the device: in_dev uint32[6n], out_dev uint32[4n].
+ * The generator behind domain randomisation, observation noise and replay sampling; exposed for known-answer tests. */
+int tvc_debug_philox(const uint32_t* in_dev, uint32_t* out_dev, int32_t n, void* stream);
+
 /* ------------------------------------------------------------------ SAC learner (K3-K7, K11) */
 
 typedef struct tvc_sac tvc_sac;

@@ -1,0 +1,158 @@
+"""Edge cases of the vector env the reference's (stale) tests describe: masked / hard reset, truncation at the episode
+cap, state export/import round trip, Philox known answers, observation-noise statistics, N=1 wrapper with curiosity."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_env(n, **kw):
+    from tvc_ai_amd import VecRocketTVCEnv
+    return VecRocketTVCEnv(n, device="cuda:0", **kw)
+
+
+def philox_numpy(ctr, key):
+    """Philox4x32-10 as published (Salmon et al., SC'11 / Random123), independent numpy restatement."""
+    M0, M1, W0, W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+    c = [int(x) for x in ctr]
+    k = [int(x) for x in key]
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [((p1 >> 32) ^ c[1] ^ k[0]) & 0xFFFFFFFF, p1 & 0xFFFFFFFF, ((p0 >> 32) ^ c[3] ^ k[1]) & 0xFFFFFFFF, p0 & 0xFFFFFFFF]
+        k = [(k[0] + W0) & 0xFFFFFFFF, (k[1] + W1) & 0xFFFFFFFF]
+    return c
+
+
+def test_philox_known_answers():
+    import ctypes as C
+    from tvc_ai_amd import _native as nat
+    L = nat.load()
+    # Random123 kat_vectors, philox4x32 10 rounds
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    rng = np.random.default_rng(1)
+    rand = rng.integers(0, 2 ** 32, (64, 6), dtype=np.uint64)
+    inp = np.array([list(c) + list(k) for c, k, _ in kat] + rand.tolist(), dtype=np.uint32)
+    t_in = torch.from_numpy(inp.astype(np.int64)).to(torch.int64).cuda()
+    t_in32 = (t_in & 0xFFFFFFFF).to(torch.int32) if False else torch.from_numpy(inp.view(np.int32)).cuda()
+    out = torch.zeros((inp.shape[0], 4), dtype=torch.int32, device="cuda")
+    nat.check(L.tvc_debug_philox(t_in32.data_ptr(), out.data_ptr(), inp.shape[0], torch.cuda.current_stream().cuda_stream))
+    got = out.cpu().numpy().view(np.uint32)
+    for i, (c, k, exp) in enumerate(kat):
+        assert philox_numpy(c, k) == list(exp), "numpy restatement disagrees with the published vector"
+        assert got[i].tolist() == list(exp)
+    for i in range(64):
+        assert got[3 + i].tolist() == philox_numpy(rand[i, :4], rand[i, 4:])
+
+
+def test_masked_soft_and_hard_reset():
+    n = 200
+    env = make_env(n, auto_reset=0)
+    env.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for _ in range(15):
+        env.step(torch.rand((n, 2), device="cuda", generator=g) - 0.5)
+    before = env.export_state()
+    mask = (torch.arange(n) % 3 == 0).to(torch.uint8).cuda()
+    obs_before = env.obs.clone()
+    obs, _ = env.reset(mask=mask)
+    after = env.export_state()
+    m = mask.bool().cpu().numpy()
+    aux_b, aux_a = before["aux"].cpu().numpy(), after["aux"].cpu().numpy()
+    # unmasked envs untouched (state and returned observation rows)
+    assert torch.equal(before["dyn"][~mask.bool()], after["dyn"][~mask.bool()])
+    assert (aux_b[~m] == aux_a[~m]).all() and torch.equal(obs[~mask.bool()], obs_before[~mask.bool()])
+    # masked envs: dynamic state re-initialised, step/phase/success cleared, episode counter +1 ...
+    assert (after["dyn"][mask.bool()].cpu().numpy() == np.array([0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0], np.float32)).all()
+    assert (aux_a[m][:, :3] == 0).all() and (aux_a[m][:, 7] == aux_b[m][:, 7] + 1).all()
+    # ... while what the reference keeps across reset() survives (success window, reward history, previous action)
+    assert (aux_a[m][:, 3:7] == aux_b[m][:, 3:7]).all()
+    assert torch.equal(before["prev_action"], after["prev_action"]) and torch.equal(before["hist"], after["hist"])
+    # hard reset == a freshly constructed env object
+    env.reset(hard=True)
+    fresh = make_env(n, auto_reset=0)
+    a, b = env.export_state(), fresh.export_state()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    env.close()
+    fresh.close()
+
+
+def test_truncation_at_episode_cap_and_auto_reset():
+    n, cap = 130, 25
+    env = make_env(n, max_episode_steps=cap, contact=0, want_final_obs=True)
+    env.reset()
+    # hover-ish start high above the ground so that nothing terminates before the cap
+    st = env.export_state()
+    dyn = st["dyn"].clone()
+    dyn[:, 2] = 10.0
+    env.import_state(dyn=dyn)
+    zero = torch.zeros((n, 2), device="cuda")
+    for t in range(1, cap + 1):
+        obs, rew, term, trunc, info = env.step(zero)
+        assert int(term.sum()) == 0
+        assert int(trunc.sum()) == (n if t == cap else 0)
+        if t < cap:
+            assert abs(float(obs[0, 9]) - t / cap) < 1e-6  # mission progress = step / max_episode_steps
+    assert torch.allclose(info["final_observation"][:, 9], torch.ones(n, device="cuda"))
+    aux = env.export_state()["aux"].cpu().numpy()
+    assert (aux[:, 0] == 0).all() and (aux[:, 7] == 2).all()  # auto-reset: step 0 of episode 2
+    assert float(obs[0, 9]) == 0.0 and float(obs[0, 7]) == 1.0  # fresh episode: progress 0, fuel 1
+    env.close()
+
+
+def test_export_import_round_trip_is_bit_exact():
+    n = 257
+    g = torch.Generator(device="cuda").manual_seed(3)
+    acts = torch.rand((40, n, 2), device="cuda", generator=g) * 1.2 - 0.6
+    for window in (10, 1000):
+        a = make_env(n, distinct_window=window, dr_enabled=1, dr_mass_var=0.2, dr_wind_std=1.0, seed=9)
+        a.reset()
+        for t in range(20):
+            a.step(acts[t])
+        snap = a.export_state()
+        b = make_env(n, distinct_window=window, dr_enabled=1, dr_mass_var=0.2, dr_wind_std=1.0, seed=9)
+        b.import_state(**{"dyn": snap["dyn"], "aux": snap["aux"], "prev_action": snap["prev_action"], "params": snap["params"],
+                          "hist": snap["hist"]})
+        for t in range(20, 40):
+            oa, ra, ta, tra, _ = a.step(acts[t])
+            ob, rb_, tb, trb, _ = b.step(acts[t])
+            assert torch.equal(oa, ob) and torch.equal(ra, rb_) and torch.equal(ta, tb) and torch.equal(tra, trb), (window, t)
+        a.close()
+        b.close()
+
+
+def test_observation_noise_statistics():
+    n = 20000
+    noisy = make_env(n, dr_enabled=1, dr_obs_noise_std=0.02, seed=5, contact=0)
+    clean = make_env(n, contact=0)
+    noisy.reset()
+    clean.reset()
+    a = torch.zeros((n, 2), device="cuda")
+    o1, *_ = noisy.step(a)
+    o2, *_ = clean.step(a)
+    d = (o1 - o2).cpu().numpy()
+    assert np.abs(d[:, 7:]).max() == 0.0                       # fuel / phase / progress are not sensors
+    assert np.all(np.abs(d[:, :7].std(axis=0) - 0.02) < 0.001) and np.all(np.abs(d[:, :7].mean(axis=0)) < 0.001)
+    assert abs(np.corrcoef(d[:, 0], d[:, 1])[0, 1]) < 0.03
+    noisy.close()
+    clean.close()
+
+
+def test_n1_wrapper_with_curiosity_and_factories():
+    from tvc_ai_amd import make_training_env, make_evaluation_env
+    env = make_training_env()
+    ev = make_evaluation_env()
+    o1, _ = env.reset(seed=1)
+    o2, _ = ev.reset(seed=1)
+    np.testing.assert_array_equal(o1, o2)
+    a = np.array([0.1, -0.05], dtype=np.float32)
+    r_first = env.step(a)[1]
+    e_first = ev.step(a)[1]
+    assert abs(r_first - e_first) < 1e-6           # no curiosity bonus on the first step of an episode (env/...:496)
+    r2, e2 = env.step(a)[1], ev.step(a)[1]
+    assert r2 > e2 and (r2 - e2) < 1.0            # 0.01 * mse of an untrained forward model: small and positive
+    env.close()
+    ev.close()

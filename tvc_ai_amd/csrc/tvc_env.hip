@@ -204,6 +204,14 @@ __global__ void env_import_kernel(EnvBuf b, int W, const float* dyn, const int* 
     store_regs<true, true>(r, hw, b, i, 100);
 }
 
+__global__ void philox_debug_kernel(const unsigned* __restrict__ in, unsigned* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned o[4];
+    philox4x32_10(in[6 * i], in[6 * i + 1], in[6 * i + 2], in[6 * i + 3], in[6 * i + 4], in[6 * i + 5], o);
+    for (int k = 0; k < 4; ++k) out[4 * i + k] = o[k];
+}
+
 // info dict of _get_enhanced_info (ref :723-742) as a tensor
 __global__ void env_info_kernel(EnvBuf b, DevCfg c, float* info) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -449,6 +457,15 @@ int tvc_env_info(tvc_env* e, float* info_dev, void* stream) {
     TVC_HIP_CHECK(hipSetDevice(e->device));
     hipLaunchKernelGGL(env_info_kernel, dim3(tvc::ceil_div(e->n, 256)), dim3(256), 0, (hipStream_t)stream, e->buf, e->dc,
                        info_dev);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Philox4x32-10 of n (counter, key) pairs on the device: in[6n] = c0 c1 c2 c3 k0 k1, out[4n] (known-answer tests of the
+// generator the reset / observation-noise / replay kernels draw from)
+int tvc_debug_philox(const uint32_t* in_dev, uint32_t* out_dev, int32_t n, void* stream) {
+    if (!in_dev || !out_dev || n < 1) return tvc::set_error(TVC_EINVAL, "bad argument");
+    hipLaunchKernelGGL(philox_debug_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in_dev, out_dev, n);
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }
