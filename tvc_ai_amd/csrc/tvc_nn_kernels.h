@@ -93,11 +93,26 @@ __device__ __forceinline__ void gemm_store_tile(float (*S)[GLD], const float (&r
 
 template <bool A_KC, bool B_KC>
 __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[GBM][GLD];
-    __shared__ __attribute__((aligned(16))) float Bs[GBN][GLD];
+    // one LDS block: the A/B k-tiles during the main loop, then the 64x64 output tile for the wide-store epilogue
+    constexpr int CLD = GBN + 4;
+    __shared__ __attribute__((aligned(16))) float smem[GBM * CLD];
+    float (*As)[GLD] = reinterpret_cast<float (*)[GLD]>(smem);
+    float (*Bs)[GLD] = reinterpret_cast<float (*)[GLD]>(smem + GBM * GLD);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+    // XCD-aware tile order (guide T1): workgroups are dealt round-robin over the 8 XCDs, each with its own L2, so the
+    // gridDim.x column tiles that re-read one 64-row slab of A are remapped onto ONE XCD instead of 4-8 different ones
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int gx = gridDim.x, nwg = gx * gridDim.y;
+        if ((nwg & 7) == 0) {
+            const int lin = blockIdx.x + gx * blockIdx.y;
+            const int swz = (lin & 7) * (nwg >> 3) + (lin >> 3);
+            bx = swz % gx;
+            by = swz / gx;
+        }
+    }
+    const int m0 = by * GBM, n0 = bx * GBN;
     const long z = blockIdx.z;
     const float* A = g.A + z * g.gA;
     const float* A2 = g.A2 ? g.A2 + z * g.gA2 : nullptr;
@@ -157,6 +172,53 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     const float* Radd = g.Radd ? g.Radd + z * g.gR : nullptr;
     const float* dZ = g.dactZ ? g.dactZ + z * g.gDZ : nullptr;
     float* colsum = g.colsum ? g.colsum + z * g.gCol : nullptr;
+    // wide path (full, aligned tile): the accumulator layout gives each lane 4-byte stores 64 B apart; staging the tile
+    // through LDS turns them into 16-byte stores of 256-byte row segments (guide T21)
+    const bool wide = a_rows_full && b_rows_full && colsum == nullptr && (g.ldc & 3) == 0 && (g.N & 3) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(Zout) |
+                        reinterpret_cast<uintptr_t>(Radd) | reinterpret_cast<uintptr_t>(dZ) |
+                        reinterpret_cast<uintptr_t>(g.rowtab)) & 15) == 0;
+    if (wide) {
+        float (*Cs)[CLD] = reinterpret_cast<float (*)[CLD]>(smem);
+        __syncthreads();  // every wave is done reading the last k-tile
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cs[wr * 32 + i * 16 + (lane >> 4) * 4 + r][wc * 32 + j * 16 + (lane & 15)] = acc[i][j][r];
+        __syncthreads();
+        const int rl = tid >> 2, cq = (tid & 3) * 16;
+        const int row = m0 + rl;
+        const long o0 = (long)row * g.ldc + n0 + cq;
+        const float* rt = g.rowtab ? g.rowtab + (long)min(row, g.rowtab_rows - 1) * g.N + n0 + cq : nullptr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = *reinterpret_cast<const float4*>(&Cs[rl][cq + 4 * q]);
+            if (bias) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bias + n0 + cq + 4 * q);
+                v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+            }
+            if (rt) {
+                const float4 t4 = *reinterpret_cast<const float4*>(rt + 4 * q);
+                v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
+            }
+            const long o = o0 + 4 * q;
+            if (Zout) *reinterpret_cast<float4*>(Zout + o) = v;
+            v.x = act_f(v.x, g.act); v.y = act_f(v.y, g.act); v.z = act_f(v.z, g.act); v.w = act_f(v.w, g.act);
+            if (Radd) {
+                const float4 r4 = *reinterpret_cast<const float4*>(Radd + o);
+                v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+            }
+            if (dZ) {
+                const float4 z4 = *reinterpret_cast<const float4*>(dZ + o);
+                v.x *= act_grad(z4.x, g.dact); v.y *= act_grad(z4.y, g.dact);
+                v.z *= act_grad(z4.z, g.dact); v.w *= act_grad(z4.w, g.dact);
+            }
+            *reinterpret_cast<float4*>(C + o) = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wc * 32 + j * 16 + (lane & 15);
