@@ -276,6 +276,141 @@ __device__ __forceinline__ float gemm_epi_value(const GemmArgs& g, const GemmEpi
     return v;
 }
 
+// ------------------------------------------------------------------ acting-path fused Linear (+act, +residual) + LayerNorm
+// One workgroup owns 32 complete output rows (N = 256 or 512 columns, 4 waves x 64*JT/4 ... see JT below), so the
+// LayerNorm that follows the Linear in every block of the actor (norm1 / norm2 / policy_head LN, optionally
+// feature_norm right behind norm2) is applied in the epilogue: the [M,N] pre-norm activation never goes to HBM.
+// Inference only (nothing is saved for backward).  A, B k-contiguous and 16-byte aligned, K % 16 == 0.
+struct RowLnArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    const float* bias; int act;
+    const float* Radd;                    // residual added before the norm (ldc)
+    const float* gamma; const float* beta;
+    const float* gamma2; const float* beta2;  // optional second LayerNorm
+};
+
+template <int JT>  // 16-column MFMA tiles per wave; N = 4 waves * JT * 16  (JT = 4 -> 256, JT = 8 -> 512)
+__device__ __forceinline__ void rowln_normalize(f32x4 (&u)[2][JT], float* red, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, int wave, int lane, int N) {
+    // u[i][j][r]: row i*16 + (lane>>4)*4 + r, column wave*16*JT + j*16 + (lane&15).  Two-pass mean / variance like torch.
+    const int q = lane >> 4, l15 = lane & 15;
+    float mean[2][4], rstd[2][4];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = 0.0f;
+#pragma unroll
+                for (int j = 0; j < JT; ++j) {
+                    const float d = pass == 0 ? u[i][j][r] : u[i][j][r] - mean[i][r];
+                    s += pass == 0 ? d : d * d;
+                }
+                s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+                if (l15 == 0) red[wave * 32 + i * 16 + q * 4 + r] = s;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = i * 16 + q * 4 + r;
+                const float t = (red[rl] + red[32 + rl] + red[64 + rl] + red[96 + rl]) / (float)N;
+                if (pass == 0) mean[i][r] = t;
+                else rstd[i][r] = rsqrtf(t + 1e-5f);
+            }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const int col = wave * 16 * JT + j * 16 + l15;
+        const float gm = gamma[col], bt = beta[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[i][j][r] = (u[i][j][r] - mean[i][r]) * rstd[i][r] * gm + bt;
+    }
+}
+
+template <int JT>
+__global__ void __launch_bounds__(256) gemm_rowln_kernel(RowLnArgs g) {
+    constexpr int N = 64 * JT;  // 4 waves x JT tiles x 16 columns
+    __shared__ __attribute__((aligned(16))) float As[32][GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[N][GLD];
+    __shared__ float red[128];
+    typedef const f32x4* cv4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * 32;
+    const int lr = tid >> 2, lk = (tid & 3) * 4;  // loader: row lr (+64p for B), k offset lk
+    const float* ap = g.A + (long)min(m0 + (lr & 31), g.M - 1) * g.lda + lk;
+    const float* bp = g.B + (long)lr * g.ldb + lk;
+    f32x4 acc[2][JT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 ra = *(cv4)ap, rb[JT];
+#pragma unroll
+    for (int p = 0; p < JT; ++p) rb[p] = *(cv4)(bp + (long)(64 * p) * g.ldb);
+    const int nk = g.K / GBK;
+    const int l15 = lane & 15, fk = (lane >> 4) * 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        if (tid < 128) *(f32x4*)&As[lr][lk] = ra;
+#pragma unroll
+        for (int p = 0; p < JT; ++p) *(f32x4*)&Bs[lr + 64 * p][lk] = rb[p];
+        __syncthreads();
+        if (kt + 1 < nk) {
+            const int ko = (kt + 1) * GBK;
+            ra = *(cv4)(ap + ko);
+#pragma unroll
+            for (int p = 0; p < JT; ++p) rb[p] = *(cv4)(bp + (long)(64 * p) * g.ldb + ko);
+        }
+        f32x4 a4[2], b4[JT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a4[i] = *(cv4)&As[i * 16 + l15][fk];
+#pragma unroll
+        for (int j = 0; j < JT; ++j) b4[j] = *(cv4)&Bs[wave * 16 * JT + j * 16 + l15][fk];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < JT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i][c], b4[j][c], acc[i][j], 0, 0, 0);
+    }
+    // epilogue: bias, activation, residual -> LayerNorm (-> second LayerNorm) -> store
+    const int q = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const int col = wave * 16 * JT + j * 16 + l15;
+        const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = act_f(acc[i][j][r] + bv, g.act);
+                if (g.Radd) v += g.Radd[(long)min(m0 + i * 16 + q * 4 + r, g.M - 1) * g.ldc + col];
+                acc[i][j][r] = v;
+            }
+    }
+    rowln_normalize<JT>(acc, red, g.gamma, g.beta, wave, lane, N);
+    if (g.gamma2) rowln_normalize<JT>(acc, red, g.gamma2, g.beta2, wave, lane, N);
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const int col = wave * 16 * JT + j * 16 + l15;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + i * 16 + q * 4 + r;
+                if (row < g.M) g.C[(long)row * g.ldc + col] = acc[i][j][r];
+            }
+    }
+}
+
 // ------------------------------------------------------------------ skinny GEMM (update path, M = batch = a few hundred)
 // 32x32 output tile per workgroup; the four waves split K and stream their MFMA fragments straight from global /
 // L2 into registers (no LDS staging, no barrier in the k-loop: with so few rows there is no reuse to stage for,

@@ -171,6 +171,7 @@ struct Ctx {
     std::vector<long> gY;                       // group stride (elements) per buffer
 };
 
+constexpr int kFuseLnMinRows = 1024;  // acting batches at least this large use the fused Linear+LayerNorm kernel
 static int g_force_variant = 0;  // diagnostics: 0 auto, 1 = 64x64 LDS-tiled, 3 = skinny split-K
 
 static void launch_gemm(bool a_kc, bool b_kc, const GemmArgs& g, int G, hipStream_t st) {
@@ -209,6 +210,25 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
         const int out = i + 1;
         const float* in = o.src == 0 ? X : c.Y[o.src];
         const long gin = o.src == 0 ? gX : c.gY[o.src];
+        // acting pass (nothing saved, many rows): Linear (+act, +residual) and the LayerNorm(s) behind it in ONE launch
+        if (o.type == OP_LINEAR && !save && G == 1 && M >= kFuseLnMinRows && !o.rowtab && (o.in_dim % GBK) == 0 &&
+            (o.out_dim == 256 || o.out_dim == 512) && i + 1 < (int)nd.ops.size() && nd.ops[i + 1].type == OP_LN &&
+            nd.ops[i + 1].src == out && nd.last_use[out] == i + 1) {
+            const Op& ln = nd.ops[i + 1];
+            const bool two = i + 2 < (int)nd.ops.size() && nd.ops[i + 2].type == OP_LN && nd.ops[i + 2].src == out + 1 &&
+                             nd.last_use[out + 1] == i + 2;
+            RowLnArgs a{};
+            a.A = in; a.B = (o.ext ? Pext : P) + o.w; a.C = c.Y[out + (two ? 2 : 1)];
+            a.M = M; a.N = o.out_dim; a.K = o.in_dim; a.lda = o.in_dim; a.ldb = o.in_dim; a.ldc = o.out_dim;
+            a.bias = (o.ext ? Pext : P) + o.b; a.act = o.act;
+            a.Radd = o.res >= 0 ? (o.res == 0 ? X : c.Y[o.res]) : nullptr;
+            a.gamma = P + ln.w; a.beta = P + ln.b;
+            if (two) { a.gamma2 = P + nd.ops[i + 2].w; a.beta2 = P + nd.ops[i + 2].b; }
+            if (o.out_dim == 256) hipLaunchKernelGGL((gemm_rowln_kernel<4>), dim3((M + 31) / 32), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((gemm_rowln_kernel<8>), dim3((M + 31) / 32), dim3(256), 0, st, a);
+            i += two ? 2 : 1;
+            continue;
+        }
         if (o.type == OP_LINEAR) {
             GemmArgs g{};
             g.A = in; g.B = (o.ext ? Pext : P) + o.w; g.C = c.Y[out];
@@ -521,7 +541,7 @@ static void ctx_alloc_train(Ctx& c, const NetDef& nd, int M, int G, char*& p) {
     }
 }
 // inference: activations rotate through a few slots (a buffer's slot is reused once its last consumer ran)
-static int ctx_alloc_infer(Ctx& c, const NetDef& nd, int M, char*& p, int max_slots = 6) {
+static int ctx_alloc_infer(Ctx& c, const NetDef& nd, int M, char*& p, int max_slots = 8) {
     const size_t nb = nd.buf_dim.size();
     c.M = M; c.G = 1;
     c.Y.assign(nb, nullptr); c.dY.assign(nb, nullptr); c.Z.assign(nb, nullptr);
@@ -529,13 +549,15 @@ static int ctx_alloc_infer(Ctx& c, const NetDef& nd, int M, char*& p, int max_sl
     int maxd = 0;
     for (size_t b = 1; b < nb; ++b) maxd = std::max(maxd, nd.buf_dim[b]);
     std::vector<float*> slot(max_slots);
-    std::vector<int> free_at(max_slots, -1);  // op index after which the slot is free
+    std::vector<int> free_at(max_slots, -1000);  // op index of the last reader of the slot (never used: far past)
     for (int s = 0; s < max_slots; ++s) slot[s] = (float*)carve(p, (long)M * maxd * 4);
     for (size_t b = 1; b < nb; ++b) {
         const int prod = (int)b - 1;
         int pick = -1;
         for (int s = 0; s < max_slots; ++s)
-            if (free_at[s] < prod) { pick = s; break; }  // its last reader ran before this op
+            // reusable once its last reader ran at least two ops earlier: a fused Linear+LN(+LN) launch writes the
+            // buffer of op i+2 while it still reads the inputs of op i
+            if (free_at[s] < prod - 2) { pick = s; break; }
         if (pick < 0) return -1;
         c.Y[b] = slot[pick];
         c.gY[b] = (long)M * nd.buf_dim[b];
@@ -615,7 +637,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     const int B = cfg->batch_size, A = cfg->act_dim, NA = cfg->max_act_rows;
     int maxd = 0;
     for (size_t b = 1; b < h->actor.buf_dim.size(); ++b) maxd = std::max(maxd, h->actor.buf_dim[b]);
-    long bytes = ctx_bytes(h->actor, B, 1, true) + ctx_bytes(h->critic, B, 2, true) + 6L * NA * maxd * 4;
+    long bytes = ctx_bytes(h->actor, B, 1, true) + ctx_bytes(h->critic, B, 2, true) + 8L * NA * maxd * 4;
     bytes += (long)cfg->pe_rows * cfg->d_model * 4 + (long)B * (cfg->obs_dim + A) * 4 * 2 + (long)B * 64 + (1 << 16);
     bytes += 256L * (4 * (h->actor.buf_dim.size() + h->critic.buf_dim.size()) * 3 + 64);
     bytes += (long)std::max(1, h->fold.layers) * ((long)h->fold.d * h->fold.d + h->fold.d + 4) * 4 + 1024;
@@ -963,7 +985,7 @@ int tvc_mlp_create(const int32_t* dims, int32_t n_layers, int32_t act, int32_t m
     h->params = params_dev; h->device = device; h->max_rows = max_rows; h->in_dim = dims[0]; h->out_dim = dims[n_layers];
     int maxd = dims[0];
     for (int l = 1; l <= n_layers; ++l) maxd = std::max(maxd, (int)dims[l]);
-    const long bytes = 8L * (((long)max_rows * maxd * 4 + 255) & ~255L) + 4096;
+    const long bytes = 10L * (((long)max_rows * maxd * 4 + 255) & ~255L) + 4096;
     hipError_t he = hipMalloc(&h->slab, bytes);
     if (he != hipSuccess) {
         delete h;
