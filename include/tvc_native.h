@@ -165,7 +165,7 @@ typedef struct tvc_sac_cfg {
     int32_t batch_size;             /* update batch rows (256) */
     int32_t max_act_rows;           /* largest batch tvc_sac_act will see */
     int32_t pe_rows;                /* 1: PE(0) on every row (== reference at B=1); >1: the reference's
-                                       batch-row-indexed table, rows >= pe_rows reuse the last */
+                                       batch-row-indexed table, row index taken modulo pe_rows */
     float gamma, alpha, tau, lr;    /* 0.99, 0.2, 0.005, 3e-4  (agent/...:971,998,1005,623-625) */
     float adam_b1, adam_b2, adam_eps; /* torch.optim.Adam defaults */
     int32_t _pad;
@@ -207,7 +207,8 @@ int tvc_sac_act(tvc_sac* sac, const float* obs_dev, int32_t n, const float* eps_
  * all-reduce gradients between them (data parallel, K10):
  *   critic_grads: target y, q1/q2 forward + backward -> grads[q1|q2], losses[0..1]
  *   critic_apply: Adam on q1, q2 (gradients multiplied by grad_scale first, e.g. 1/world_size)
- *   actor_grads : policy forward, q(s, a_new) through the UPDATED critics, backward -> grads[policy], losses[2]
+ *   actor_grads : policy forward (shared with critic_grads: one pass over [s ; s'] when both phases of an update
+ *                 see the same s), q(s, a_new) through the UPDATED critics, backward -> grads[policy], losses[2]
  *   actor_apply : Adam on the policy, Polyak update of both targets
  * s, s2 float[B,obs]; a float[B,A]; r, d float[B] (d = done as 0/1 float; the reference's BoolTensor
  * `dones` raises inside its update); eps_next / eps_new float[B,A] standard-normal draws;

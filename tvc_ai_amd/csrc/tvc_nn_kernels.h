@@ -36,7 +36,7 @@ struct GemmArgs {
     int M, N, K, K1;
     long lda, lda2, ldb, ldc;
     const float* bias;      // [N]
-    const float* rowtab;    // [rowtab_rows, N], row min(m, rows-1) added (positional-encoding table)
+    const float* rowtab;    // [rowtab_rows, N], row (m mod rows) added (positional-encoding table)
     int rowtab_rows;
     float* Zout;            // pre-activation copy (for backward), ldc
     int act;                // applied after bias/rowtab
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
         const int rl = tid >> 2, cq = (tid & 3) * 16;
         const int row = m0 + rl;
         const long o0 = (long)row * g.ldc + n0 + cq;
-        const float* rt = g.rowtab ? g.rowtab + (long)min(row, g.rowtab_rows - 1) * g.N + n0 + cq : nullptr;
+        const float* rt = g.rowtab ? g.rowtab + (long)(row % g.rowtab_rows) * g.N + n0 + cq : nullptr;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 v = *reinterpret_cast<const float4*>(&Cs[rl][cq + 4 * q]);
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
                 const int row = m0 + wr * 32 + i * 16 + (lane >> 4) * 4 + r;
                 if (cok && row < g.M) {
                     float v = acc[i][j][r] + bv;
-                    if (g.rowtab) v += g.rowtab[(long)min(row, g.rowtab_rows - 1) * g.N + col];
+                    if (g.rowtab) v += g.rowtab[(long)(row % g.rowtab_rows) * g.N + col];
                     const long o = (long)row * g.ldc + col;
                     if (Zout) Zout[o] = v;
                     v = act_f(v, g.act);
@@ -267,7 +267,7 @@ __device__ __forceinline__ GemmEpi gemm_epi_ptrs(const GemmArgs& g, long z) {
 }
 __device__ __forceinline__ float gemm_epi_value(const GemmArgs& g, const GemmEpi& e, float acc, int row, int col) {
     float v = acc + (e.bias ? e.bias[col] : 0.0f);
-    if (g.rowtab) v += g.rowtab[(long)min(row, g.rowtab_rows - 1) * g.N + col];
+    if (g.rowtab) v += g.rowtab[(long)(row % g.rowtab_rows) * g.N + col];
     const long o = (long)row * g.ldc + col;
     if (e.Zout) e.Zout[o] = v;
     v = act_f(v, g.act);

@@ -500,6 +500,8 @@ struct tvc_sac {
     float *params, *grads, *adam_m, *adam_v;  // caller-owned
     void* slab = nullptr;                      // library-owned workspace
     Ctx actx, cctx, ictx;                      // actor (train), critics (train, G=2), actor (inference, slot-aliased)
+    float *xs2 = nullptr;   // [2B, obs]: states and next states stacked for the single actor forward of an update
+    bool actor_fwd_valid = false;
     float *pe = nullptr, *xcat = nullptr, *a_tmp = nullptr, *y = nullptr, *dq = nullptr, *ls_tmp = nullptr, *mean_tmp = nullptr;
     int* step = nullptr;   // [2]: critics, actor
     float* bc = nullptr;   // [4]
@@ -637,7 +639,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     const int B = cfg->batch_size, A = cfg->act_dim, NA = cfg->max_act_rows;
     int maxd = 0;
     for (size_t b = 1; b < h->actor.buf_dim.size(); ++b) maxd = std::max(maxd, h->actor.buf_dim[b]);
-    long bytes = ctx_bytes(h->actor, B, 1, true) + ctx_bytes(h->critic, B, 2, true) + 8L * NA * maxd * 4;
+    long bytes = ctx_bytes(h->actor, 2 * B, 1, true) + ctx_bytes(h->critic, B, 2, true) + 8L * NA * maxd * 4 + 2L * B * cfg->obs_dim * 4 + 512;
     bytes += (long)cfg->pe_rows * cfg->d_model * 4 + (long)B * (cfg->obs_dim + A) * 4 * 2 + (long)B * 64 + (1 << 16);
     bytes += 256L * (4 * (h->actor.buf_dim.size() + h->critic.buf_dim.size()) * 3 + 64);
     bytes += (long)std::max(1, h->fold.layers) * ((long)h->fold.d * h->fold.d + h->fold.d + 4) * 4 + 1024;
@@ -648,7 +650,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     }
     (void)hipMemset(h->slab, 0, bytes);
     char* p = (char*)h->slab;
-    ctx_alloc_train(h->actx, h->actor, B, 1, p);
+    ctx_alloc_train(h->actx, h->actor, 2 * B, 1, p);
     ctx_alloc_train(h->cctx, h->critic, B, 2, p);
     if (ctx_alloc_infer(h->ictx, h->actor_inf, NA, p) != 0) {
         (void)hipFree(h->slab);
@@ -657,6 +659,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     }
     h->pe = (float*)carve(p, (long)cfg->pe_rows * cfg->d_model * 4);
     h->xcat = (float*)carve(p, (long)B * (cfg->obs_dim + A) * 4);
+    h->xs2 = (float*)carve(p, 2L * B * cfg->obs_dim * 4);
     h->a_tmp = (float*)carve(p, (long)B * A * 4);
     h->ls_tmp = (float*)carve(p, (long)B * A * 4);
     h->mean_tmp = (float*)carve(p, (long)B * A * 4);
@@ -728,10 +731,16 @@ int tvc_sac_critic_grads(tvc_sac* h, const float* s, const float* a, const float
     const float* pe = c.family == 0 ? h->pe : nullptr;
     TVC_HIP_CHECK(hipMemsetAsync(losses, 0, 4 * sizeof(float), st));
     hipLaunchKernelGGL(physics_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, st, s, a, s2, losses, B, no, A, 0.1f);
+    // ONE actor forward over [s ; s'] (2B rows): the policy parameters do not change between the target pass on s'
+    // (here) and the policy pass on s (tvc_sac_actor_grads), so the rows of s are computed -- and saved for the
+    // backward -- now, and the positional-encoding table is indexed modulo its rows
+    TVC_HIP_CHECK(hipMemcpyAsync(h->xs2, s, (long)B * no * 4, hipMemcpyDeviceToDevice, st));
+    TVC_HIP_CHECK(hipMemcpyAsync(h->xs2 + (long)B * no, s2, (long)B * no * 4, hipMemcpyDeviceToDevice, st));
+    net_forward(h->actor, h->P_actor(), 0, h->xs2, 0, 2 * B, 1, h->actx, true, pe, c.pe_rows, st);
+    h->actor_fwd_valid = true;
     // target: a' ~ pi(s'), y = r + gamma (1-d) min(tq1, tq2)(s', a')
-    net_forward(h->actor, h->P_actor(), 0, s2, 0, B, 1, h->actx, false, pe, c.pe_rows, st);
-    hipLaunchKernelGGL(sample_action_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, h->actx.Y.back(), eps_next, h->a_tmp,
-                       (float*)nullptr, (float*)nullptr, B, A, 0);
+    hipLaunchKernelGGL(sample_action_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, h->actx.Y.back() + (long)B * 2 * A,
+                       eps_next, h->a_tmp, (float*)nullptr, (float*)nullptr, B, A, 0);
     hipLaunchKernelGGL(concat_kernel, dim3((B * nin + 255) / 256), dim3(256), 0, st, s2, h->a_tmp, h->xcat, B, no, A);
     net_forward(h->critic, h->P_tq(), h->n_critic, h->xcat, 0, B, 2, h->cctx, false, nullptr, 0, st);
     hipLaunchKernelGGL(td_target_kernel, dim3((B + 255) / 256), dim3(256), 0, st, h->cctx.Y.back(), r, d, h->y, B, c.gamma);
@@ -769,7 +778,13 @@ int tvc_sac_actor_grads(tvc_sac* h, const float* s, const float* eps_new, float*
     const tvc_sac_cfg& c = h->cfg;
     const int B = c.batch_size, A = c.act_dim, no = c.obs_dim, nin = no + A;
     const float* pe = c.family == 0 ? h->pe : nullptr;
-    net_forward(h->actor, h->P_actor(), 0, s, 0, B, 1, h->actx, true, pe, c.pe_rows, st);
+    const float* xin = s;
+    if (h->actor_fwd_valid) {  // rows [0, B) of the stacked forward made by tvc_sac_critic_grads of this update
+        xin = h->xs2;
+        h->actor_fwd_valid = false;
+    } else {
+        net_forward(h->actor, h->P_actor(), 0, s, 0, B, 1, h->actx, true, pe, c.pe_rows, st);
+    }
     const float* head = h->actx.Y.back();
     hipLaunchKernelGGL(sample_action_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, head, eps_new, h->a_tmp, h->mean_tmp,
                        h->ls_tmp, B, A, 0);
@@ -782,7 +797,7 @@ int tvc_sac_actor_grads(tvc_sac* h, const float* s, const float* eps_new, float*
     hipLaunchKernelGGL(actor_head_grad_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, h->cctx.dY[0], h->cctx.gY[0], nin, no,
                        head, eps_new, h->actx.dY.back(), B, A, c.alpha);
     TVC_HIP_CHECK(hipMemsetAsync(h->G_actor(), 0, h->n_actor * sizeof(float), st));
-    net_backward(h->actor, h->P_actor(), 0, h->G_actor(), 0, s, 0, B, 1, h->actx, false, st);
+    net_backward(h->actor, h->P_actor(), 0, h->G_actor(), 0, xin, 0, B, 1, h->actx, false, st);
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }
