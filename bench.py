@@ -91,19 +91,6 @@ def max_over_ranks(x, world, device):
     return float(t.item())
 
 
-def kernel_event_times(fn_step, n_launch, device):
-    """Average duration of ONE launch, HIP events on the stream the kernel is launched on."""
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_launch)]
-    torch.cuda.synchronize(device)
-    for k in range(n_launch):
-        evs[k][0].record()
-        fn_step(k)
-        evs[k][1].record()
-    torch.cuda.synchronize(device)
-    ts = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3  # us
-    return float(np.mean(ts)), float(np.median(ts)), float(np.min(ts))
-
-
 def cpu_baseline(seconds):
     """The fp64 oracle (oracle/tvc_oracle.c, kind 'port') stepping envs on the host cores, same step
     semantics (contact, auto-reset, 10-entry diversity window), pre-sampled U(-1,1)^2 actions."""

@@ -196,6 +196,11 @@ void tvc_sac_destroy(tvc_sac* sac);
  * (initialisation, checkpoint load, parameter broadcast). */
 int tvc_sac_sync_derived(tvc_sac* sac, void* stream);
 
+/* Adam step counters {critics, actor} (device-resident so that a captured update keeps counting); checkpoints only,
+ * both calls synchronise. */
+int tvc_sac_get_adam_steps(tvc_sac* sac, int32_t out[2]);
+int tvc_sac_set_adam_steps(tvc_sac* sac, const int32_t in[2]);
+
 /* Policy part of get_action (agent/...:765-789) for n rows: mean/log_std (clamped to [-20,2]) and
  * action = clamp(mean + exp(log_std) * eps, -1, 1); eps_dev NULL = deterministic (action = clamp(mean)).
  * flags bit 0: do not clamp (the safety layer sees the raw sample, agent/...:780-789).

@@ -237,3 +237,39 @@ def test_fused_linear_kernel_vs_torch_fp32(M, N, K):
                                               torch.cuda.current_stream().cuda_stream))
             err = (Y - ref).abs().max().item()
             assert err <= 1e-5 * max(1.0, K ** 0.5), (M, N, K, act, variant, err)
+
+
+def test_checkpoint_layout_and_round_trip(tmp_path):
+    """save_checkpoint keeps the reference's key layout (agent/multi_algorithm_agent.py:1098-1141) and tensor shapes
+    (names/shapes of the reference nets: tests/golden/sac_ref_meta.json); load -> identical deterministic actions
+    (the reference's own integration test asks for atol 1e-6) and identical next update."""
+    from tvc_ai_amd.agent import MultiAlgorithmAgent
+    meta = json.load(open(os.path.join(HERE, "golden", "sac_ref_meta.json")))
+    cfg = {"tvc_native": {"batch_size": 32, "max_act_rows": 64}}
+    a = MultiAlgorithmAgent(10, 2, cfg, seed=1)
+    g = torch.Generator().manual_seed(0)
+    mk = lambda: {"states": torch.randn(32, 10, generator=g), "actions": torch.rand(32, 2, generator=g) * 2 - 1,
+                  "rewards": torch.randn(32, generator=g), "next_states": torch.randn(32, 10, generator=g),
+                  "dones": torch.rand(32, generator=g) < 0.1}
+    for _ in range(3):
+        assert "error" not in a.update(mk())
+    path = str(tmp_path / "ckpt.pth")
+    a.save_checkpoint(path)
+    ck = torch.load(path, map_location="cpu", weights_only=True)
+    sac = ck["algorithms"]["sac"]
+    assert set(sac) >= {"policy_state", "q1_state", "q2_state", "target_q1_state", "target_q2_state", "type"} and sac["type"] == "sac"
+    assert set(ck) >= {"algorithms", "performance_history", "algorithm_weights", "config"}
+    for net, key in (("policy", "policy_state"), ("q1", "q1_state"), ("q2", "q2_state")):
+        for name, shape in meta["nets"][net]:
+            if name.startswith("value_head"):
+                continue  # never created by the SAC path unless imported from a reference checkpoint
+            assert name in sac[key] and list(sac[key][name].shape) == shape, (net, name)
+    assert sac["native_adam"]["steps"] == [3, 3]
+    b = MultiAlgorithmAgent(10, 2, cfg, seed=99)
+    b.load_checkpoint(path)
+    obs = torch.randn(16, 10)
+    act_a, _ = a.get_action(obs, deterministic=True)
+    act_b, _ = b.get_action(obs, deterministic=True)
+    np.testing.assert_allclose(act_a, act_b, atol=1e-6)
+    assert torch.equal(a.sac.params, b.sac.params) and torch.equal(a.sac.adam_v, b.sac.adam_v)
+    assert b.sac.adam_steps() == [3, 3]

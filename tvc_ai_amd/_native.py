@@ -78,6 +78,8 @@ SIGNATURES.update({
                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "tvc_sac_create": (C.c_int, [C.POINTER(SacCfg), C.c_int32, _VP, _VP, _VP, _VP, _VP, C.POINTER(_VP)]),
     "tvc_sac_destroy": (None, [_VP]),
+    "tvc_sac_get_adam_steps": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
+    "tvc_sac_set_adam_steps": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
     "tvc_sac_sync_derived": (C.c_int, [_VP, _VP]),
     "tvc_sac_act": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, C.c_int32, _VP]),
     "tvc_mlp_param_count": (C.c_int64, [C.POINTER(C.c_int32), C.c_int32]),

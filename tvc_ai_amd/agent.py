@@ -163,6 +163,14 @@ class NativeSAC:
         self.params[n0 + 2 * nc:n0 + 4 * nc].copy_(self.params[n0:n0 + 2 * nc])
         self.sync_derived()
 
+    def adam_steps(self):
+        out = (C.c_int32 * 2)()
+        nat.check(self.L.tvc_sac_get_adam_steps(self._h, out))
+        return [int(out[0]), int(out[1])]
+
+    def set_adam_steps(self, steps):
+        nat.check(self.L.tvc_sac_set_adam_steps(self._h, (C.c_int32 * 2)(int(steps[0]), int(steps[1]))))
+
     def sync_derived(self):
         """call after writing `params` from the host side (folded acting weights are cached in the handle)"""
         nat.check(self.L.tvc_sac_sync_derived(self._h, self._stream()))
@@ -433,7 +441,7 @@ class MultiAlgorithmAgent:
                 "q1_state": s.export_reference_state("q1"), "q2_state": s.export_reference_state("q2"),
                 "target_q1_state": s.export_reference_state("target_q1"),
                 "target_q2_state": s.export_reference_state("target_q2"),
-                "native_adam": {"m": s.adam_m.cpu(), "v": s.adam_v.cpu()},
+                "native_adam": {"m": s.adam_m.cpu(), "v": s.adam_v.cpu(), "steps": s.adam_steps()},
                 "type": "sac"}},
             "performance_history": {k: list(v) for k, v in self.performance_history.items()},
             "algorithm_weights": self.algorithm_weights,
@@ -451,3 +459,5 @@ class MultiAlgorithmAgent:
         if "native_adam" in d:
             self.sac.adam_m.copy_(d["native_adam"]["m"])
             self.sac.adam_v.copy_(d["native_adam"]["v"])
+            if "steps" in d["native_adam"]:
+                self.sac.set_adam_steps(d["native_adam"]["steps"])

@@ -4,7 +4,7 @@
 //   nn.Linear (+bias, GELU / ReLU, residual)            -> gemm_kernel (fused epilogues)
 //   nn.LayerNorm forward / backward                      -> layernorm_fwd_kernel / layernorm_bwd_kernel
 //   Linear(hidden -> 2A) / Linear(hidden -> 1) heads     -> head_fwd_kernel / head_bwd_kernel (dot-reductions, no MFMA)
-//   torch.optim.Adam.step, Polyak soft update            -> adam_kernel / polyak_kernel
+//   torch.optim.Adam.step, Polyak soft update            -> adam_dev_kernel (tvc_sac.hip) / polyak_kernel
 // Numerics: v_mfma_f32_16x16x4_f32 is an exact-f32 k-ordered fma chain (no TF32 on gfx950), so results
 // match torch fp32 to summation-order rounding.
 #pragma once
@@ -711,17 +711,6 @@ __global__ void __launch_bounds__(256) head_bwd_dw_kernel(HeadBwdArgs a) {
 }
 
 // ------------------------------------------------------------------ optimiser
-// torch.optim.Adam defaults written out (agent/...:623-625): p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            long n, float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float gscale) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale;
-        const float mi = b1 * m[i] + (1.0f - b1) * gi;
-        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
-    }
-}
 // target = tau * online + (1 - tau) * target   (agent/...:1005-1010)
 __global__ void polyak_kernel(float* __restrict__ tgt, const float* __restrict__ src, long n, float tau) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)

@@ -821,6 +821,21 @@ static void refresh_folded(tvc_sac* h, hipStream_t st) {
     launch_gemm(true, true, b, f.layers, st);
 }
 
+// Adam step counters (critics, actor) live on the device so that a captured update keeps counting; these two calls
+// synchronise and are meant for checkpoints only
+int tvc_sac_get_adam_steps(tvc_sac* h, int32_t out[2]) {
+    if (!h || !out) return tvc::set_error(TVC_EINVAL, "null argument");
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    TVC_HIP_CHECK(hipMemcpy(out, h->step, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+int tvc_sac_set_adam_steps(tvc_sac* h, const int32_t in[2]) {
+    if (!h || !in) return tvc::set_error(TVC_EINVAL, "null argument");
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    TVC_HIP_CHECK(hipMemcpy(h->step, in, 2 * sizeof(int), hipMemcpyHostToDevice));
+    return 0;
+}
+
 int tvc_sac_sync_derived(tvc_sac* h, void* stream) {
     if (!h) return tvc::set_error(TVC_EINVAL, "null argument");
     TVC_HIP_CHECK(hipSetDevice(h->device));
