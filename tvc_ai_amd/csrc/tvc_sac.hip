@@ -475,6 +475,8 @@ __global__ void adam_tick_kernel(int* step, float* bc, float b1, float b2) {
     bc[0] = (float)(1.0 - pow((double)b1, (double)t));
     bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
 }
+// torch.optim.Adam defaults written out (agent/...:623-625): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps); g is pre-scaled by gscale (1 / world size)
 __global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                 long n, float lr, float b1, float b2, float eps, const float* __restrict__ bc, float gscale) {
     const float bc1 = bc[0], bc2s = bc[1];
