@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--dr-stage", type=int, default=None, help="train: domain randomisation at curriculum stage 0-5 (default: off)")
     ap.add_argument("--no-overlap", action="store_true", help="train: run the update after the acting pass instead of beside it")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per K steps")
+    ap.add_argument("--graph", action="store_true", help="train: capture the K steps in one hipGraph (default: eager; the host "
+                                                         "stays ahead of the device, both measure the same)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample length (0 = skip)")
     ap.add_argument("--roofline-envs", type=int, default=1 << 22, help="bandwidth-regime size for the extra roofline point")
     return ap.parse_args()
@@ -199,7 +201,10 @@ def main():
     torch.cuda.synchronize(device)
 
     graph = None
-    use_graph = not args.no_graph and not (world > 1 and workload == "train")
+    # physics: one kernel per step -> capture the K launches in one hipGraph (removes the per-launch host cost).
+    # train: ~200 launches per step; eager keeps the graph size independent of K (a 1000-step graph would hold 200k
+    # nodes) and measures the same as a captured loop because the host stays ahead of the device
+    use_graph = (not args.no_graph) and (workload == "physics" or (args.graph and world == 1))
     # multi-GPU train: the two gradient all-reduces (RCCL) sit between kernel phases; they are issued eagerly
     # rather than captured (collective capture is not something a 1-GPU gpurun box can validate)
     if use_graph:
