@@ -93,7 +93,7 @@ def max_over_ranks(x, world, device):
     return float(t.item())
 
 
-def cpu_baseline(seconds):
+def cpu_baseline(seconds, n_envs=0):
     """The fp64 oracle (oracle/tvc_oracle.c, kind 'port') stepping envs on the host cores, same step
     semantics (contact, auto-reset, 10-entry diversity window), pre-sampled U(-1,1)^2 actions."""
     from concurrent.futures import ThreadPoolExecutor
@@ -154,6 +154,26 @@ def cpu_baseline(seconds):
             n_up += 1
         out["sac_updates_per_s"] = n_up / (time.perf_counter() - t0)
         out["sac_sample"] = f"{n_up} updates, eager PyTorch fp32 restatement, {cores} threads, B=256, reference shapes"
+        # acting half: policy forward on a bounded sample of rows, then the same loop the GPU runs
+        # (act on n envs -> n env-steps -> one update) assembled from the three measured CPU rates
+        rows = 4096
+        obs = torch.randn(rows, 10)
+        with torch.no_grad():
+            st.actor_forward(P, obs)
+            t0 = time.perf_counter()
+            n_fw = 0
+            while time.perf_counter() - t0 < max(1.0, seconds * 0.2):
+                st.actor_forward(P, obs)
+                n_fw += 1
+        act_rows_per_s = n_fw * rows / (time.perf_counter() - t0)
+        out["act_rows_per_s"] = act_rows_per_s
+        if n_envs:
+            t_step = n_envs / out["value"] + n_envs / act_rows_per_s + 1.0 / out["sac_updates_per_s"]
+            out["env_only_value"] = out["value"]
+            out["value"] = n_envs / t_step
+            out["sample"] += (f"; train-loop value = {n_envs} envs / (env {n_envs / out['env_only_value'] * 1e3:.1f} ms + act "
+                              f"{n_envs / act_rows_per_s * 1e3:.1f} ms + update {1e3 / out['sac_updates_per_s']:.1f} ms) per vector step, "
+                              f"policy forward timed on {rows} rows")
     except Exception as e:
         out["sac_updates_per_s"] = None
         out["sac_sample"] = f"failed: {e}"
@@ -270,7 +290,7 @@ def main():
             out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
         if args.cpu_seconds > 0:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, n if workload == "train" else 0)
             except Exception as e:
                 out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)

@@ -175,6 +175,15 @@ class VecRocketTVCEnv:
         info = {"final_observation": self.final_obs} if self.final_obs is not None else {}
         return obs, self.rew, self.term, self.trunc, info
 
+    @staticmethod
+    def observation_view(obs: torch.Tensor, mode: int = 10) -> torch.Tensor:
+        """Column views of the 10-wide observation for the other widths the reference mentions:
+        10 = shipped env (quat4, omega3, fuel, phase, progress); 8 = legacy tests / curiosity input (quat4, omega3,
+        fuel); 7 = README (quat4, omega3).  No copy."""
+        if mode not in (7, 8, 10):
+            raise ValueError("obs mode must be 7, 8 or 10")
+        return obs[:, :mode]
+
     def step_many(self, actions: torch.Tensor, out=None):
         """T steps in one launch with pre-supplied actions [T,N,2] (tests/benchmark.py:40-60 procedure)."""
         T = actions.shape[0]
