@@ -391,6 +391,31 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
             sac.close()
         except Exception as e:
             rep["sac_learner_only"] = {"error": str(e)}
+        # BASELINE configs[0] through the drop-in surface: ONE env (EnhancedRocketTVCEnv wrapper) + MultiAlgorithmAgent,
+        # the loop of scripts/train.py:535-620 (get_action -> step -> B=1 update with a BoolTensor `dones`), numpy in/out
+        try:
+            from tvc_ai_amd import EnhancedRocketTVCEnv
+            from tvc_ai_amd.agent import MultiAlgorithmAgent
+            env1 = EnhancedRocketTVCEnv(enable_curiosity=True, device=device)
+            ag = MultiAlgorithmAgent(10, 2, {"tvc_native": {"batch_size": 1, "max_act_rows": 16},
+                                             "physics_informed": {"enabled": True}}, device=device)
+            obs, _ = env1.reset()
+            n1 = 0
+            t0 = time.perf_counter()
+            while n1 < 300 and time.perf_counter() - t0 < 10.0:
+                a, _ = ag.get_action(torch.from_numpy(obs).unsqueeze(0))
+                nobs, r, term, trunc, _ = env1.step(a.flatten())
+                ag.update({"states": torch.from_numpy(obs).unsqueeze(0), "actions": torch.from_numpy(a),
+                           "rewards": torch.tensor([r]), "next_states": torch.from_numpy(nobs).unsqueeze(0),
+                           "dones": torch.BoolTensor([term or trunc])})
+                obs = env1.reset()[0] if (term or trunc) else nobs
+                n1 += 1
+            rep["reference_plumbing_n1"] = {"steps_per_s": n1 / (time.perf_counter() - t0), "steps": n1,
+                                            "note": "1 env + 1 online SAC update per step through the reference's Python surface "
+                                                    "(host round trips every call); reference docs imply 35-93 steps/s (BASELINE.md)"}
+            env1.close()
+        except Exception as e:
+            rep["reference_plumbing_n1"] = {"error": str(e)}
     try:  # the integrator in its bandwidth regime (H3: small batches are launch/latency-bound)
         rep["roofline_integrator_large_n"] = integrator_roofline(args.roofline_envs, device)
     except Exception as e:  # never lose the headline line to the optional point
