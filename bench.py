@@ -326,10 +326,12 @@ def graph_time_us(fn, reps, device, rounds=5):
     return best
 
 
-def pmc_traffic(n):
+def pmc_traffic(n, kernel="env_step_kernel"):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, both in
+    KiB; tools/pmc_to_json.py), keyed by kernel and grid size in threads; None when that size was not profiled."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get("env_step_kernel", {}).get(str(n), {}).get("hbm_bytes_per_launch")
+            return json.load(f).get(kernel, {}).get(str(n), {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
 
@@ -371,7 +373,8 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
                                                              torch.cuda.current_stream(device).cuda_stream), 20, device)
         tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
         rep["roofline"] = {"bound": "mfma", "kernel": "tvcnn::gemm_kernel<true,true> (Linear 256->256, M = envs)", "achieved": tf,
-                           "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF, "traffic": None,
+                           "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                           "traffic": pmc_traffic((N // 64) * ((M + 63) // 64) * 256, "tvcnn::gemm_kernel"),
                            "launch_us": us, "flops_per_launch": 2.0 * M * N * K, "dtype": "f32 in / f32 acc MFMA"}
         del X, W, b, Y
         rep["roofline_integrator"] = integrator_roofline(n, device)

@@ -1,13 +1,27 @@
-"""Workload for rocprofv3 --pmc passes: a few eager env_step launches at two sizes."""
+"""Workload for rocprofv3 --pmc passes.
+  pmc_run.py env 8192 65536 4194304   -> eager env_step launches at those sizes
+  pmc_run.py gemm 65536 256 256       -> the acting-pass Linear kernel at M N K (tvc_nn_linear_forward)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from tvc_ai_amd import VecRocketTVCEnv
-sizes = [int(x) for x in (sys.argv[1:] or ["8192", "4194304"])]
-for n in sizes:
-    env = VecRocketTVCEnv(n); env.reset()
-    acts = (torch.rand((4, n, 2), device="cuda") * 2 - 1).contiguous()
-    for k in range(40):
-        env.step(acts[k % 4])
+mode = sys.argv[1] if len(sys.argv) > 1 else "env"
+if mode == "gemm":
+    from tvc_ai_amd import _native as nat
+    L = nat.load()
+    M, N, K = [int(x) for x in sys.argv[2:5]]
+    X = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.zeros(N, device="cuda")
+    Y = torch.empty(M, N, device="cuda")
+    for _ in range(20):
+        nat.check(L.tvc_nn_linear_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, N, K, 0, 0,
+                                          torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
-    env.close()
+else:
+    from tvc_ai_amd import VecRocketTVCEnv
+    sizes = [int(x) for x in (sys.argv[2:] or ["8192", "4194304"])]
+    for n in sizes:
+        env = VecRocketTVCEnv(n); env.reset()
+        acts = (torch.rand((4, n, 2), device="cuda") * 2 - 1).contiguous()
+        for k in range(40):
+            env.step(acts[k % 4])
+        torch.cuda.synchronize()
+        env.close()

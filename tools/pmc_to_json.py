@@ -22,12 +22,12 @@ fetch = collect(sys.argv[1], "FETCH_SIZE")
 write = collect(sys.argv[2], "WRITE_SIZE")
 out = defaultdict(dict)
 for (name, grid), f in fetch.items():
-    if (name, grid) not in write or "env_step" not in name:
+    if (name, grid) not in write or not ("env_step" in name or "gemm_kernel" in name):
         continue
     w = write[(name, grid)]
     out[name][str(grid)] = {"fetch_size_kib_raw": f, "write_size_kib": w, "hbm_read_bytes": f * 1024 * 2,
                             "hbm_write_bytes": w * 1024, "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024,
-                            "hbm_bytes_per_env_step": (f * 1024 * 2 + w * 1024) / grid}
+                            "hbm_bytes_per_thread": (f * 1024 * 2 + w * 1024) / grid}
 path = sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic.json"
 json.dump(out, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))
