@@ -420,11 +420,9 @@ __global__ void __launch_bounds__(256) gemm_rowln_kernel(RowLnArgs g) {
 // operands with ld % 4 == 0): loads are unconditional.  Otherwise addresses are clamped into range and the value is
 // zero-selected AFTER the load -- never a branch around a load (hipcc would wait vmcnt(0) per element, guide 5 item 4c).
 template <bool A_KC, bool B_KC, bool FAST>
-__global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g) {
-    __shared__ float red[4][32 * 33];
+__device__ __forceinline__ void skinny_body(const GemmArgs& g, int bx, int by, long z, float (*red)[32 * 33]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    const long z = blockIdx.z;
+    const int m0 = by * 32, n0 = bx * 32;
     const float* A = g.A + z * g.gA;
     const float* B = g.B + z * g.gB;
     const int ksteps = (g.K + 15) / 16;
@@ -519,6 +517,160 @@ __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g) {
             atomicAdd(&e.colsum[n0 + tid], sum);
         }
     }
+}
+template <bool A_KC, bool B_KC, bool FAST>
+__global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g) {
+    __shared__ float red[4][32 * 33];
+    skinny_body<A_KC, B_KC, FAST>(g, blockIdx.x, blockIdx.y, blockIdx.z, red);
+}
+// Backward of one Linear at batch size in ONE launch: workgroups [0, nw) compute dW = dZ^T X (both operands
+// m-contiguous), the others dX = dZ W (+ residual gradient, act', bias column sums).  The two products share dZ and
+// nothing else, so running them side by side halves the launch count of the backward chain (latency-bound, H5).
+struct GemmPair {
+    GemmArgs w, x;
+    int nw, w_tiles_x, x_tiles_x;
+};
+template <bool FAST>
+__global__ void __launch_bounds__(256) gemm_skinny_bwd_kernel(GemmPair p) {
+    __shared__ float red[4][32 * 33];
+    int b = blockIdx.x;
+    if (b < p.nw) {
+        skinny_body<false, false, FAST>(p.w, b % p.w_tiles_x, b / p.w_tiles_x, blockIdx.z, red);
+    } else {
+        b -= p.nw;
+        skinny_body<true, false, FAST>(p.x, b % p.x_tiles_x, b / p.x_tiles_x, blockIdx.z, red);
+    }
+}
+
+// ------------------------------------------------------------------ thin Linear: in_dim <= 16 (observation / [s | a] input layers)
+// K = 10 or 12 is neither a multiple of the MFMA k-step nor 16-byte aligned, so the MFMA kernels fall on their
+// bounds-checked slow path (11-23 us at batch 256, 64 us at 65 536 rows).  These are plain FMA kernels: one thread
+// per output column (forward), per weight row (dW), one wave per row (dX); the optional second source X2 reads the
+// critic input [s | a] in place (no concat kernel).
+struct ThinArgs {
+    const float* X; const float* X2;   // columns [0, K1) from X (row stride ldx), [K1, K) from X2 (row stride ldx2)
+    int ldx, ldx2;
+    const float* W; const float* bias; // W[N, K], bias[N]
+    const float* rowtab; int rowtab_rows;
+    float* Y; float* Z;                // forward: Y = act(Z), Z optional (pre-activation for backward)
+    const float* dZ; float* dW; float* dX;
+    int M, N, K, K1, act;
+    long gX, gX2, gW, gB, gY, gDW, gDX;  // group strides (blockIdx.z)
+};
+constexpr int THIN_K = 16, THIN_ROWS = 8;
+__device__ __forceinline__ float thin_x(const ThinArgs& a, const float* X, const float* X2, int row, int k) {
+    // clamped address, zero-selected after the load (never a branch around a load)
+    const int kc = min(k, a.K - 1), rc = min(row, a.M - 1);
+    const bool second = X2 != nullptr && kc >= a.K1;
+    const float* p = second ? X2 + (long)rc * a.ldx2 + (kc - a.K1) : X + (long)rc * a.ldx + min(kc, a.K1 - 1);
+    const float v = *p;
+    return (k < a.K && row < a.M) ? v : 0.0f;
+}
+__global__ void __launch_bounds__(256) thin_fwd_kernel(ThinArgs a) {
+    __shared__ float xs[THIN_ROWS][THIN_K];
+    const int tid = threadIdx.x, n = blockIdx.y * 256 + tid, row0 = blockIdx.x * THIN_ROWS;
+    const long z = blockIdx.z;
+    const float* X = a.X + z * a.gX;
+    const float* X2 = a.X2 ? a.X2 + z * a.gX2 : nullptr;
+    if (tid < THIN_ROWS * THIN_K) xs[tid / THIN_K][tid % THIN_K] = thin_x(a, X, X2, row0 + tid / THIN_K, tid % THIN_K);
+    const int nc = min(n, a.N - 1);
+    const float* W = a.W + z * a.gW + (long)nc * a.K;
+    float w[THIN_K];
+#pragma unroll
+    for (int k = 0; k < THIN_K; ++k) {
+        const float v = W[min(k, a.K - 1)];
+        w[k] = k < a.K ? v : 0.0f;
+    }
+    const float b = a.bias ? a.bias[z * a.gB + nc] : 0.0f;
+    __syncthreads();
+    if (n >= a.N) return;
+    float* Y = a.Y + z * a.gY;
+    float* Z = a.Z ? a.Z + z * a.gY : nullptr;
+#pragma unroll
+    for (int r = 0; r < THIN_ROWS; ++r) {
+        const int row = row0 + r;
+        if (row >= a.M) break;
+        float v = b;
+#pragma unroll
+        for (int k = 0; k < THIN_K; ++k) v = fmaf(xs[r][k], w[k], v);
+        if (a.rowtab) v += a.rowtab[(long)(row % a.rowtab_rows) * a.N + n];
+        const long o = (long)row * a.N + n;
+        if (Z) Z[o] = v;
+        Y[o] = act_f(v, a.act);
+    }
+}
+// dW[n, k] = sum_m dZ[m, n] X[m, k]: 32 weight rows per workgroup, the 8 half-waves split the batch rows
+__global__ void __launch_bounds__(256) thin_wgrad_kernel(ThinArgs a) {
+    __shared__ float xs[64][THIN_K];
+    __shared__ float red[8][32][THIN_K + 1];
+    const int tid = threadIdx.x, l = tid & 31, rg = tid >> 5;
+    const int n = blockIdx.x * 32 + l, nc = min(n, a.N - 1);
+    const long z = blockIdx.z;
+    const float* X = a.X + z * a.gX;
+    const float* X2 = a.X2 ? a.X2 + z * a.gX2 : nullptr;
+    const float* dZ = a.dZ + z * a.gY;
+    float acc[THIN_K];
+#pragma unroll
+    for (int k = 0; k < THIN_K; ++k) acc[k] = 0.0f;
+    for (int m0 = 0; m0 < a.M; m0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + i * 256;
+            xs[e / THIN_K][e % THIN_K] = thin_x(a, X, X2, m0 + e / THIN_K, e % THIN_K);
+        }
+        __syncthreads();
+        float dz[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + rg + i * 8;
+            const float v = dZ[(long)min(m, a.M - 1) * a.N + nc];
+            dz[i] = m < a.M ? v : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int k = 0; k < THIN_K; ++k) acc[k] = fmaf(dz[i], xs[rg + i * 8][k], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < THIN_K; ++k) red[rg][l][k] = acc[k];
+    __syncthreads();
+    float* dW = a.dW + z * a.gDW;
+    for (int e = tid; e < 32 * a.K; e += 256) {
+        const int nl = e / a.K, k = e - nl * a.K;
+        if (blockIdx.x * 32 + nl >= a.N) break;
+        float s = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) s += red[g][nl][k];
+        dW[(long)(blockIdx.x * 32 + nl) * a.K + k] = s;
+    }
+}
+// dX[m, k] = sum_n dZ[m, n] W[n, k]: one wave per row
+__global__ void __launch_bounds__(256) thin_dgrad_kernel(ThinArgs a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.M) return;
+    const long z = blockIdx.z;
+    const float* dZ = a.dZ + z * a.gY + (long)row * a.N;
+    const float* W = a.W + z * a.gW;
+    float acc[THIN_K];
+#pragma unroll
+    for (int k = 0; k < THIN_K; ++k) acc[k] = 0.0f;
+    for (int n0 = 0; n0 < a.N; n0 += 64) {
+        const int n = n0 + lane, nc = min(n, a.N - 1);
+        const float dv = dZ[nc];
+        const float dz = n < a.N ? dv : 0.0f;
+#pragma unroll
+        for (int k = 0; k < THIN_K; ++k) acc[k] = fmaf(dz, W[(long)nc * a.K + min(k, a.K - 1)], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < THIN_K; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+    float* dX = a.dX + z * a.gDX + (long)row * a.K;
+    float mine = 0.0f;
+#pragma unroll
+    for (int k = 0; k < THIN_K; ++k) mine = lane == k ? acc[k] : mine;
+    if (lane < a.K) dX[lane] = mine;
 }
 
 // ------------------------------------------------------------------ LayerNorm (eps 1e-5, biased variance): one wave per row
@@ -639,11 +791,22 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(LnBwdArgs a) {
             *reinterpret_cast<float4*>(a.dX + off + c) = make_float4(o4[0], o4[1], o4[2], o4[3]);
         }
     }
+    // column sums (dgamma, dbeta, bias gradient of the producing Linear): the four waves are reduced through LDS
+    // first, so a block issues one float atomic per column and sum instead of four (same-address atomics from
+    // 32+ blocks serialise in L2 and were 2/3 of this kernel's time)
+    __shared__ float red[3][4][VPL * 64];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = (i / 4) * 256 + lane * 4 + (i & 3);
-        if (a.dgamma) { atomicAdd(a.dgamma + z * a.gP + c, dg[i]); atomicAdd(a.dbeta + z * a.gP + c, db[i]); }
-        if (a.colsum) atomicAdd(a.colsum + z * a.gP + c, cs[i]);
+        red[0][wave][c] = dg[i]; red[1][wave][c] = db[i]; red[2][wave][c] = cs[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < VPL * 64; c += 256) {
+        if (a.dgamma) {
+            atomicAdd(a.dgamma + z * a.gP + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+            atomicAdd(a.dbeta + z * a.gP + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        }
+        if (a.colsum) atomicAdd(a.colsum + z * a.gP + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
     }
 }
 

@@ -202,14 +202,54 @@ static void launch_gemm(bool a_kc, bool b_kc, const GemmArgs& g, int G, hipStrea
     else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, st, g);
 }
 
+// dW = dZ^T X and dX = dZ W of one Linear in one launch when both fit the split-K kernel's fast path
+static void launch_gemm_bwd_pair(const GemmArgs& w, const GemmArgs& x, int G, hipStream_t st) {
+    auto fast = [](const GemmArgs& g) {
+        return ((g.lda & 3) == 0) && ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
+               ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) && (g.M % 32) == 0 && (g.N % 32) == 0 && (g.K % 16) == 0 &&
+               ((g.gA | g.gB) & 3) == 0 && g.A2 == nullptr && (long)g.M * g.N <= 512L * 512L;
+    };
+    if (g_force_variant != 0 || !fast(w) || !fast(x)) {
+        launch_gemm(false, false, w, G, st);
+        launch_gemm(true, false, x, G, st);
+        return;
+    }
+    GemmPair p;
+    p.w = w; p.x = x;
+    p.w_tiles_x = w.N / 32; p.x_tiles_x = x.N / 32;
+    p.nw = p.w_tiles_x * (w.M / 32);
+    const int nx = p.x_tiles_x * (x.M / 32);
+    hipLaunchKernelGGL((gemm_skinny_bwd_kernel<true>), dim3(p.nw + nx, 1, G), dim3(256), 0, st, p);
+}
+
+// optional second input source of a net whose first layer reads a concatenation [X[:, :K1] | X2[:, :in_dim-K1]]
+struct In2 { const float* X2; long gX2; int K1, ldx, ldx2; };
+static ThinArgs thin_input(const Op& o, const float* X, long gX, const In2* in2, int M) {
+    ThinArgs a{};
+    a.X = X; a.gX = gX; a.K = o.in_dim; a.M = M; a.N = o.out_dim;
+    a.K1 = in2 ? in2->K1 : o.in_dim; a.ldx = in2 ? in2->ldx : o.in_dim;
+    a.X2 = in2 ? in2->X2 : nullptr; a.ldx2 = in2 ? in2->ldx2 : 0; a.gX2 = in2 ? in2->gX2 : 0;
+    return a;
+}
+static bool thin_ok(const Op& o) { return o.type == OP_LINEAR && o.src == 0 && o.in_dim <= THIN_K && o.res < 0; }
+
 // forward of one net (G parameter groups batched through blockIdx.z).  X: [G?][M,in]; gX = 0 shares one input.
 static void net_forward(const NetDef& nd, const float* P, long gP, const float* X, long gX, int M, int G, Ctx& c, bool save,
-                        const float* pe, int pe_rows, hipStream_t st, const float* Pext = nullptr) {
+                        const float* pe, int pe_rows, hipStream_t st, const float* Pext = nullptr, const In2* in2 = nullptr) {
     for (int i = 0; i < (int)nd.ops.size(); ++i) {
         const Op& o = nd.ops[i];
         const int out = i + 1;
         const float* in = o.src == 0 ? X : c.Y[o.src];
         const long gin = o.src == 0 ? gX : c.gY[o.src];
+        if (thin_ok(o) && g_force_variant == 0) {  // input layer (in_dim <= 16): plain-FMA kernel, reads [X | X2] in place
+            ThinArgs a = thin_input(o, X, gX, in2, M);
+            a.W = P + o.w; a.bias = P + o.b; a.gW = gP; a.gB = gP;
+            if (o.rowtab && pe) { a.rowtab = pe; a.rowtab_rows = pe_rows; }
+            a.Y = c.Y[out]; a.gY = c.gY[out]; a.act = o.act;
+            a.Z = (save && o.act != ACT_NONE) ? c.Z[out] : nullptr;
+            hipLaunchKernelGGL(thin_fwd_kernel, dim3((M + THIN_ROWS - 1) / THIN_ROWS, (o.out_dim + 255) / 256, G), dim3(256), 0, st, a);
+            continue;
+        }
         // acting pass (nothing saved, many rows): Linear (+act, +residual) and the LayerNorm(s) behind it in ONE launch
         if (o.type == OP_LINEAR && !save && G == 1 && M >= kFuseLnMinRows && !o.rowtab && (o.in_dim % GBK) == 0 &&
             (o.out_dim == 256 || o.out_dim == 512) && i + 1 < (int)nd.ops.size() && nd.ops[i + 1].type == OP_LN &&
@@ -278,7 +318,7 @@ __global__ void head_bwd_dx_act_kernel(HeadBwdArgs a, const float* Zp, long gZ, 
 // backward of one net.  c.dY[last] must hold the gradient w.r.t. the head output.  Gr == nullptr: data
 // gradients only (the critics inside the actor step).  Returns the input gradient in c.dY[0] when wanted.
 static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, long gG, const float* X, long gX, int M, int G,
-                         Ctx& c, bool want_input_grad, hipStream_t st) {
+                         Ctx& c, bool want_input_grad, hipStream_t st, const In2* in2 = nullptr) {
     for (int i = (int)nd.ops.size() - 1; i >= 0; --i) {
         const Op& o = nd.ops[i];
         const int out = i + 1;
@@ -323,13 +363,27 @@ static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, l
             else hipLaunchKernelGGL((layernorm_bwd_kernel<8>), grid, block, 0, st, a);
         } else {  // LINEAR: c.dY[out] already holds dZ (act' and bias column sums were fused by its writer)
             const float* dZ = c.dY[out];
+            if (thin_ok(o) && g_force_variant == 0) {
+                ThinArgs a = thin_input(o, X, gX, in2, M);
+                a.dZ = dZ; a.gY = c.gY[out];
+                if (Gr) {
+                    a.dW = Gr + o.w; a.gDW = gG;
+                    hipLaunchKernelGGL(thin_wgrad_kernel, dim3((o.out_dim + 31) / 32, 1, G), dim3(256), 0, st, a);
+                }
+                if (want_input_grad) {
+                    a.W = P + o.w; a.gW = gP; a.dX = c.dY[0]; a.gDX = c.gY[0];
+                    hipLaunchKernelGGL(thin_dgrad_kernel, dim3((M + 3) / 4, 1, G), dim3(256), 0, st, a);
+                }
+                continue;
+            }
+            GemmArgs gw{};
             if (Gr) {  // dW[out,in] = dZ^T X
-                GemmArgs g{};
+                GemmArgs& g = gw;
                 g.A = dZ; g.B = in; g.C = Gr + o.w;
                 g.M = o.out_dim; g.N = o.in_dim; g.K = M; g.K1 = M;
                 g.lda = o.out_dim; g.ldb = o.in_dim; g.ldc = o.in_dim;
                 g.gA = c.gY[out]; g.gB = gin; g.gC = gG;
-                launch_gemm(false, false, g, G, st);
+                if (!(o.src > 0 || want_input_grad)) launch_gemm(false, false, g, G, st);
             }
             if (o.src > 0 || want_input_grad) {  // dX[M,in] = dZ W (+ residual-branch gradient) (* act' of the producer)
                 GemmArgs g{};
@@ -341,7 +395,8 @@ static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, l
                 if (rc >= 0 && rc != i) { g.Radd = c.dY[rc + 1]; g.gR = c.gY[rc + 1]; }
                 if (prod_act) { g.dactZ = c.Z[o.src]; g.dact = po->act; g.gDZ = c.gY[o.src]; }
                 if (prod_bias_grad) { g.colsum = prod_bias_grad; g.gCol = gG; }
-                launch_gemm(true, false, g, G, st);
+                if (Gr) launch_gemm_bwd_pair(gw, g, G, st);
+                else launch_gemm(true, false, g, G, st);
             }
         }
     }
@@ -441,13 +496,19 @@ __global__ void actor_head_grad_kernel(const float* __restrict__ dxin, long g_st
     dhead[(long)m * 2 * A + A + j] = pass ? (da * expf(ls) * eps[i] - alpha / (float)M) : 0.0f;
 }
 
-// PhysicsInformedLoss.forward (agent/...:236-285), reported only
-__global__ void __launch_bounds__(256) physics_loss_kernel(const float* __restrict__ s, const float* __restrict__ a,
-                                                           const float* __restrict__ s2, float* __restrict__ losses, int M,
-                                                           int no, int na, float weight) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
+// First kernel of an update.  Workgroup 0: losses[0..2] = 0 and losses[3] = PhysicsInformedLoss.forward
+// (agent/...:236-285, reported only); the other workgroups stack xs2 = [s ; s'] for the single actor forward.
+__global__ void __launch_bounds__(256) update_prep_kernel(const float* __restrict__ s, const float* __restrict__ a,
+                                                          const float* __restrict__ s2, float* __restrict__ losses,
+                                                          float* __restrict__ xs2, int M, int no, int na, float weight) {
+    if (blockIdx.x > 0) {
+        const long n = (long)M * no;
+        for (long i = (long)(blockIdx.x - 1) * 256 + threadIdx.x; i < 2 * n; i += (long)(gridDim.x - 1) * 256)
+            xs2[i] = i < n ? s[i] : s2[i - n];
+        return;
+    }
     float e = 0.f;
-    if (m < M && no >= 7) {
+    for (int m = threadIdx.x; m < M && no >= 7; m += 256) {
         const float* x = s + (long)m * no;
         const float* x2 = s2 + (long)m * no;
         float an2 = 0.f;
@@ -463,29 +524,39 @@ __global__ void __launch_bounds__(256) physics_loss_kernel(const float* __restri
         const float de = 0.5f * ke2 - (0.5f * ke + 0.5f * an2 * 0.01f);
         const float qn = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]) - 1.0f;
         const float qn2 = sqrtf(x2[0] * x2[0] + x2[1] * x2[1] + x2[2] * x2[2] + x2[3] * x2[3]) - 1.0f;
-        e = weight * (mom / (3.0f * M) + de * de / (float)M + (qn * qn + qn2 * qn2) / (float)M);
+        e += weight * (mom / (3.0f * M) + de * de / (float)M + (qn * qn + qn2 * qn2) / (float)M);
     }
     const float sum = block_sum(e);
-    if (threadIdx.x == 0) atomicAdd(&losses[3], sum);
+    if (threadIdx.x == 0) { losses[0] = 0.f; losses[1] = 0.f; losses[2] = 0.f; losses[3] = sum; }
 }
 
-// Adam bias corrections from a device-resident step counter (keeps the update hipGraph-replayable)
-__global__ void adam_tick_kernel(int* step, float* bc, float b1, float b2) {
-    const int t = ++(*step);
-    bc[0] = (float)(1.0 - pow((double)b1, (double)t));
-    bc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
-}
 // torch.optim.Adam defaults written out (agent/...:623-625): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
-// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps); g is pre-scaled by gscale (1 / world size)
-__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                long n, float lr, float b1, float b2, float eps, const float* __restrict__ bc, float gscale) {
-    const float bc1 = bc[0], bc2s = bc[1];
+// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps); g is pre-scaled by gscale (1 / world size).
+// The step counter t lives on the device (a captured update keeps counting): every workgroup reads it, the LAST one
+// to finish increments it.  The gradient is zeroed once consumed, so the next update needs no memset launch.
+__global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                       int* step, unsigned* done, float gscale) {
+    __shared__ float sbc[2];
+    const int t = *step + 1;
+    if (threadIdx.x == 0) {
+        sbc[0] = (float)(1.0 - pow((double)b1, (double)t));
+        sbc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+    }
+    __syncthreads();
+    const float bc1 = sbc[0], bc2s = sbc[1];
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
         const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
         m[i] = mi; v[i] = vi;
         p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2s + eps);
+        g[i] = 0.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(done, 1u) == gridDim.x - 1) { *step = t; *done = 0u; }
     }
 }
 
@@ -504,8 +575,9 @@ struct tvc_sac {
     Ctx actx, cctx, ictx;                      // actor (train), critics (train, G=2), actor (inference, slot-aliased)
     float *xs2 = nullptr;   // [2B, obs]: states and next states stacked for the single actor forward of an update
     bool actor_fwd_valid = false;
+    bool grads_clean[2] = {false, false};  // critics, actor: zeroed by the Adam kernel since they were last written
     float *pe = nullptr, *xcat = nullptr, *a_tmp = nullptr, *y = nullptr, *dq = nullptr, *ls_tmp = nullptr, *mean_tmp = nullptr;
-    int* step = nullptr;   // [2]: critics, actor
+    int* step = nullptr;   // [4]: Adam steps (critics, actor), then the two finished-workgroup counters of adam_dev_kernel
     float* bc = nullptr;   // [4]
     float* P_actor() { return params; }
     float* P_q() { return params + n_actor; }
@@ -717,6 +789,18 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
     return 0;
 }
 
+// critic input [s | a]: read in place by the thin first-layer kernels when it is at most 16 wide, else concatenated
+static const float* critic_input(tvc_sac* h, const float* s, const float* a, In2& in2, hipStream_t st) {
+    const int B = h->cfg.batch_size, A = h->cfg.act_dim, no = h->cfg.obs_dim;
+    if (no + A <= THIN_K) {
+        in2.X2 = a; in2.gX2 = 0; in2.K1 = no; in2.ldx = no; in2.ldx2 = A;
+        return s;
+    }
+    in2.X2 = nullptr;
+    hipLaunchKernelGGL(concat_kernel, dim3((B * (no + A) + 255) / 256), dim3(256), 0, st, s, a, h->xcat, B, no, A);
+    return h->xcat;
+}
+
 static int check_batch_ptrs(const void* a, const void* b, const void* c) {
     if (!a || !b || !c) return tvc::set_error(TVC_EINVAL, "null batch pointer");
     return 0;
@@ -729,40 +813,40 @@ int tvc_sac_critic_grads(tvc_sac* h, const float* s, const float* a, const float
     TVC_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const tvc_sac_cfg& c = h->cfg;
-    const int B = c.batch_size, A = c.act_dim, no = c.obs_dim, nin = no + A;
+    const int B = c.batch_size, A = c.act_dim, no = c.obs_dim;
     const float* pe = c.family == 0 ? h->pe : nullptr;
-    TVC_HIP_CHECK(hipMemsetAsync(losses, 0, 4 * sizeof(float), st));
-    hipLaunchKernelGGL(physics_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, st, s, a, s2, losses, B, no, A, 0.1f);
     // ONE actor forward over [s ; s'] (2B rows): the policy parameters do not change between the target pass on s'
     // (here) and the policy pass on s (tvc_sac_actor_grads), so the rows of s are computed -- and saved for the
     // backward -- now, and the positional-encoding table is indexed modulo its rows
-    TVC_HIP_CHECK(hipMemcpyAsync(h->xs2, s, (long)B * no * 4, hipMemcpyDeviceToDevice, st));
-    TVC_HIP_CHECK(hipMemcpyAsync(h->xs2 + (long)B * no, s2, (long)B * no * 4, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(update_prep_kernel, dim3(1 + (2 * B * no + 255) / 256), dim3(256), 0, st, s, a, s2, losses, h->xs2, B, no, A,
+                       0.1f);
     net_forward(h->actor, h->P_actor(), 0, h->xs2, 0, 2 * B, 1, h->actx, true, pe, c.pe_rows, st);
     h->actor_fwd_valid = true;
     // target: a' ~ pi(s'), y = r + gamma (1-d) min(tq1, tq2)(s', a')
     hipLaunchKernelGGL(sample_action_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, h->actx.Y.back() + (long)B * 2 * A,
                        eps_next, h->a_tmp, (float*)nullptr, (float*)nullptr, B, A, 0);
-    hipLaunchKernelGGL(concat_kernel, dim3((B * nin + 255) / 256), dim3(256), 0, st, s2, h->a_tmp, h->xcat, B, no, A);
-    net_forward(h->critic, h->P_tq(), h->n_critic, h->xcat, 0, B, 2, h->cctx, false, nullptr, 0, st);
+    In2 in2;
+    const float* x = critic_input(h, s2, h->a_tmp, in2, st);
+    net_forward(h->critic, h->P_tq(), h->n_critic, x, 0, B, 2, h->cctx, false, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr);
     hipLaunchKernelGGL(td_target_kernel, dim3((B + 255) / 256), dim3(256), 0, st, h->cctx.Y.back(), r, d, h->y, B, c.gamma);
     // online critics on (s, a): forward (saved), loss, backward
-    hipLaunchKernelGGL(concat_kernel, dim3((B * nin + 255) / 256), dim3(256), 0, st, s, a, h->xcat, B, no, A);
-    net_forward(h->critic, h->P_q(), h->n_critic, h->xcat, 0, B, 2, h->cctx, true, nullptr, 0, st);
+    x = critic_input(h, s, a, in2, st);
+    net_forward(h->critic, h->P_q(), h->n_critic, x, 0, B, 2, h->cctx, true, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr);
     hipLaunchKernelGGL(q_loss_kernel, dim3((B + 255) / 256, 2), dim3(256), 0, st, h->cctx.Y.back(), h->y, h->cctx.dY.back(),
                        losses, B);
-    TVC_HIP_CHECK(hipMemsetAsync(h->G_q(), 0, 2 * h->n_critic * sizeof(float), st));
-    net_backward(h->critic, h->P_q(), h->n_critic, h->G_q(), h->n_critic, h->xcat, 0, B, 2, h->cctx, false, st);
+    if (!h->grads_clean[0]) TVC_HIP_CHECK(hipMemsetAsync(h->G_q(), 0, 2 * h->n_critic * sizeof(float), st));
+    h->grads_clean[0] = false;
+    net_backward(h->critic, h->P_q(), h->n_critic, h->G_q(), h->n_critic, x, 0, B, 2, h->cctx, false, st, in2.X2 ? &in2 : nullptr);
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 static void adam_apply(tvc_sac* h, float* p, float* g, long off, long n, int which, float gscale, hipStream_t st) {
     const tvc_sac_cfg& c = h->cfg;
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, h->step + which, h->bc + 2 * which, c.adam_b1, c.adam_b2);
     const int blocks = (int)std::min<long>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, st, p, g, h->adam_m + off, h->adam_v + off, n, c.lr, c.adam_b1,
-                       c.adam_b2, c.adam_eps, h->bc + 2 * which, gscale);
+                       c.adam_b2, c.adam_eps, h->step + which, (unsigned*)(h->step + 2 + which), gscale);
+    h->grads_clean[which] = true;
 }
 
 int tvc_sac_critic_apply(tvc_sac* h, float grad_scale, void* stream) {
@@ -790,15 +874,17 @@ int tvc_sac_actor_grads(tvc_sac* h, const float* s, const float* eps_new, float*
     const float* head = h->actx.Y.back();
     hipLaunchKernelGGL(sample_action_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, head, eps_new, h->a_tmp, h->mean_tmp,
                        h->ls_tmp, B, A, 0);
-    hipLaunchKernelGGL(concat_kernel, dim3((B * nin + 255) / 256), dim3(256), 0, st, s, h->a_tmp, h->xcat, B, no, A);
-    net_forward(h->critic, h->P_q(), h->n_critic, h->xcat, 0, B, 2, h->cctx, true, nullptr, 0, st);
+    In2 in2;
+    const float* x = critic_input(h, s, h->a_tmp, in2, st);
+    net_forward(h->critic, h->P_q(), h->n_critic, x, 0, B, 2, h->cctx, true, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr);
     hipLaunchKernelGGL(actor_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, st, h->cctx.Y.back(), h->ls_tmp, eps_new,
                        h->cctx.dY.back(), losses, B, A, c.alpha);
     // data gradients only through the critics (the reference also fills q.grad here, then discards it)
-    net_backward(h->critic, h->P_q(), h->n_critic, nullptr, 0, h->xcat, 0, B, 2, h->cctx, true, st);
+    net_backward(h->critic, h->P_q(), h->n_critic, nullptr, 0, x, 0, B, 2, h->cctx, true, st, in2.X2 ? &in2 : nullptr);
     hipLaunchKernelGGL(actor_head_grad_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, h->cctx.dY[0], h->cctx.gY[0], nin, no,
                        head, eps_new, h->actx.dY.back(), B, A, c.alpha);
-    TVC_HIP_CHECK(hipMemsetAsync(h->G_actor(), 0, h->n_actor * sizeof(float), st));
+    if (!h->grads_clean[1]) TVC_HIP_CHECK(hipMemsetAsync(h->G_actor(), 0, h->n_actor * sizeof(float), st));
+    h->grads_clean[1] = false;
     net_backward(h->actor, h->P_actor(), 0, h->G_actor(), 0, xin, 0, B, 1, h->actx, false, st);
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
@@ -886,9 +972,10 @@ int tvc_sac_q_values(tvc_sac* h, const float* s, const float* a, int32_t n, int3
     if (n != h->cfg.batch_size) return tvc::set_error(TVC_EINVAL, "tvc_sac_q_values needs n == batch_size (%d)", h->cfg.batch_size);
     TVC_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    const int A = h->cfg.act_dim, no = h->cfg.obs_dim;
-    hipLaunchKernelGGL(concat_kernel, dim3((n * (no + A) + 255) / 256), dim3(256), 0, st, s, a, h->xcat, n, no, A);
-    net_forward(h->critic, use_target ? h->P_tq() : h->P_q(), h->n_critic, h->xcat, 0, n, 2, h->cctx, false, nullptr, 0, st);
+    In2 in2;
+    const float* x = critic_input(h, s, a, in2, st);
+    net_forward(h->critic, use_target ? h->P_tq() : h->P_q(), h->n_critic, x, 0, n, 2, h->cctx, false, nullptr, 0, st, nullptr,
+                in2.X2 ? &in2 : nullptr);
     TVC_HIP_CHECK(hipMemcpyAsync(q, h->cctx.Y.back(), 2L * n * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
 }
@@ -976,12 +1063,14 @@ __global__ void safety_select_kernel(const float* __restrict__ state, int sd, co
 static const float* mlp_run(tvc_mlp* h, const float* a, int lda, int k1, const float* b, int ldb, int n, hipStream_t st) {
     const int k2 = h->in_dim - k1;
     const float* in = a;
-    if (k2 > 0 || lda != h->in_dim) {
+    In2 in2{b, 0, k1, lda, ldb};
+    const bool thin = thin_ok(h->net.ops[0]);  // the first layer reads [a | b] in place
+    if (!thin && (k2 > 0 || lda != h->in_dim)) {
         hipLaunchKernelGGL(gather2_kernel, dim3((n * h->in_dim + 255) / 256), dim3(256), 0, st, a, lda, k1, b, ldb, k2, h->xcat, n);
         in = h->xcat;
     }
     for (size_t i = 1; i < h->ctx.gY.size(); ++i) h->ctx.gY[i] = (long)n * h->net.buf_dim[i];
-    net_forward(h->net, h->params, 0, in, 0, n, 1, h->ctx, false, nullptr, 0, st);
+    net_forward(h->net, h->params, 0, in, 0, n, 1, h->ctx, false, nullptr, 0, st, nullptr, thin ? &in2 : nullptr);
     return h->ctx.Y.back();
 }
 }  // namespace
