@@ -655,12 +655,24 @@ __global__ void __launch_bounds__(256) thin_dgrad_kernel(ThinArgs a) {
     float acc[THIN_K];
 #pragma unroll
     for (int k = 0; k < THIN_K; ++k) acc[k] = 0.0f;
+    const bool vec = (a.K & 3) == 0;  // weight rows are 16-byte aligned: K / 4 float4 loads per lane
+    const int kq = a.K >> 2;
     for (int n0 = 0; n0 < a.N; n0 += 64) {
         const int n = n0 + lane, nc = min(n, a.N - 1);
         const float dv = dZ[nc];
         const float dz = n < a.N ? dv : 0.0f;
+        if (vec) {
+            const float4* wr = reinterpret_cast<const float4*>(W + (long)nc * a.K);
 #pragma unroll
-        for (int k = 0; k < THIN_K; ++k) acc[k] = fmaf(dz, W[(long)nc * a.K + min(k, a.K - 1)], acc[k]);
+            for (int q = 0; q < THIN_K / 4; ++q) {
+                const float4 w = wr[min(q, kq - 1)];
+                acc[q * 4] = fmaf(dz, w.x, acc[q * 4]); acc[q * 4 + 1] = fmaf(dz, w.y, acc[q * 4 + 1]);
+                acc[q * 4 + 2] = fmaf(dz, w.z, acc[q * 4 + 2]); acc[q * 4 + 3] = fmaf(dz, w.w, acc[q * 4 + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < THIN_K; ++k) acc[k] = fmaf(dz, W[(long)nc * a.K + min(k, a.K - 1)], acc[k]);
+        }
     }
 #pragma unroll
     for (int k = 0; k < THIN_K; ++k)
@@ -864,10 +876,20 @@ __global__ void __launch_bounds__(256) head_bwd_dw_kernel(HeadBwdArgs a) {
     const int j = idx / a.K, k = idx - j * a.K;
     const int m_begin = blockIdx.z * 32, m_end = min(a.M, m_begin + 32);
     float s = 0.f, sb = 0.f;
-    for (int m = m_begin; m < m_end; ++m) {
-        const float dv = a.dOut[z * a.gD + (long)m * a.NO + j];
-        s += dv * a.X[z * a.gX + (long)m * a.K + k];
-        sb += dv;
+    for (int m0 = m_begin; m0 < m_end; m0 += 8) {  // 8 row loads in flight (clamped, zero-selected after the load)
+        float dv[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int m = min(m0 + u, a.M - 1);
+            dv[u] = a.dOut[z * a.gD + (long)m * a.NO + j];
+            xv[u] = a.X[z * a.gX + (long)m * a.K + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float d = m0 + u < m_end ? dv[u] : 0.0f;
+            s = fmaf(d, xv[u], s);
+            sb += d;
+        }
     }
     atomicAdd(&a.dW[z * a.gW + idx], s);
     if (k == 0) atomicAdd(&a.db[z * a.gB + j], sb);

@@ -250,10 +250,11 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
             hipLaunchKernelGGL(thin_fwd_kernel, dim3((M + THIN_ROWS - 1) / THIN_ROWS, (o.out_dim + 255) / 256, G), dim3(256), 0, st, a);
             continue;
         }
-        // acting pass (nothing saved, many rows): Linear (+act, +residual) and the LayerNorm(s) behind it in ONE launch
+        // acting pass (nothing saved, many rows): Linear (+act, +residual) and the LayerNorm(s) behind it in ONE launch,
+        // 32 complete rows per workgroup
         if (o.type == OP_LINEAR && !save && G == 1 && M >= kFuseLnMinRows && !o.rowtab && (o.in_dim % GBK) == 0 &&
             (o.out_dim == 256 || o.out_dim == 512) && i + 1 < (int)nd.ops.size() && nd.ops[i + 1].type == OP_LN &&
-            nd.ops[i + 1].src == out && nd.last_use[out] == i + 1) {
+            nd.ops[i + 1].src == out && nd.last_use[out] == i + 1 && g_force_variant == 0) {
             const Op& ln = nd.ops[i + 1];
             const bool two = i + 2 < (int)nd.ops.size() && nd.ops[i + 2].type == OP_LN && nd.ops[i + 2].src == out + 1 &&
                              nd.last_use[out + 1] == i + 2;
@@ -532,19 +533,15 @@ __global__ void __launch_bounds__(256) update_prep_kernel(const float* __restric
 
 // torch.optim.Adam defaults written out (agent/...:623-625): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps); g is pre-scaled by gscale (1 / world size).
-// The step counter t lives on the device (a captured update keeps counting): every workgroup reads it, the LAST one
-// to finish increments it.  The gradient is zeroed once consumed, so the next update needs no memset launch.
+// The step counter t and the running powers b1^t, b2^t (double) live on the device, so a captured update keeps
+// counting: every workgroup reads them, the LAST one to finish advances them.  The gradient is zeroed once consumed,
+// so the next update needs no memset launch.
+struct AdamClock { double b1t, b2t; int step; unsigned done; };
 __global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                       int* step, unsigned* done, float gscale) {
-    __shared__ float sbc[2];
-    const int t = *step + 1;
-    if (threadIdx.x == 0) {
-        sbc[0] = (float)(1.0 - pow((double)b1, (double)t));
-        sbc[1] = (float)sqrt(1.0 - pow((double)b2, (double)t));
-    }
-    __syncthreads();
-    const float bc1 = sbc[0], bc2s = sbc[1];
+                                                       AdamClock* clk, float gscale) {
+    const double b1t = clk->b1t * (double)b1, b2t = clk->b2t * (double)b2;  // b^t for this step (uniform)
+    const float bc1 = (float)(1.0 - b1t), bc2s = (float)sqrt(1.0 - b2t);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
@@ -556,7 +553,9 @@ __global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, fl
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        if (atomicAdd(done, 1u) == gridDim.x - 1) { *step = t; *done = 0u; }
+        if (atomicAdd(&clk->done, 1u) == gridDim.x - 1) {
+            clk->b1t = b1t; clk->b2t = b2t; clk->step += 1; clk->done = 0u;
+        }
     }
 }
 
@@ -577,8 +576,7 @@ struct tvc_sac {
     bool actor_fwd_valid = false;
     bool grads_clean[2] = {false, false};  // critics, actor: zeroed by the Adam kernel since they were last written
     float *pe = nullptr, *xcat = nullptr, *a_tmp = nullptr, *y = nullptr, *dq = nullptr, *ls_tmp = nullptr, *mean_tmp = nullptr;
-    int* step = nullptr;   // [4]: Adam steps (critics, actor), then the two finished-workgroup counters of adam_dev_kernel
-    float* bc = nullptr;   // [4]
+    AdamClock* clk = nullptr;  // [2]: critics, actor
     float* P_actor() { return params; }
     float* P_q() { return params + n_actor; }
     float* P_tq() { return params + n_actor + 2 * n_critic; }
@@ -739,8 +737,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     h->mean_tmp = (float*)carve(p, (long)B * A * 4);
     h->y = (float*)carve(p, (long)B * 4);
     h->dq = (float*)carve(p, (long)B * 2 * 4);
-    h->step = (int*)carve(p, 16);
-    h->bc = (float*)carve(p, 16);
+    h->clk = (AdamClock*)carve(p, 2 * sizeof(AdamClock));
     h->ov = (float*)carve(p, (long)std::max(1, h->fold.layers) * ((long)h->fold.d * h->fold.d + h->fold.d + 4) * 4);
     if ((long)(p - (char*)h->slab) > bytes) {
         (void)hipFree(h->slab);
@@ -758,6 +755,15 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
             (void)hipFree(h->slab);
             delete h;
             return tvc::set_error(TVC_EHIP, "hipMemcpy(pe) failed: %s", hipGetErrorString(he));
+        }
+    }
+    {
+        AdamClock c0[2] = {{1.0, 1.0, 0, 0u}, {1.0, 1.0, 0, 0u}};
+        he = hipMemcpy(h->clk, c0, sizeof(c0), hipMemcpyHostToDevice);
+        if (he != hipSuccess) {
+            (void)hipFree(h->slab);
+            delete h;
+            return tvc::set_error(TVC_EHIP, "hipMemcpy(adam clocks) failed: %s", hipGetErrorString(he));
         }
     }
     *out = h;
@@ -845,7 +851,7 @@ static void adam_apply(tvc_sac* h, float* p, float* g, long off, long n, int whi
     const tvc_sac_cfg& c = h->cfg;
     const int blocks = (int)std::min<long>((n + 255) / 256, 2048);
     hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, st, p, g, h->adam_m + off, h->adam_v + off, n, c.lr, c.adam_b1,
-                       c.adam_b2, c.adam_eps, h->step + which, (unsigned*)(h->step + 2 + which), gscale);
+                       c.adam_b2, c.adam_eps, h->clk + which, gscale);
     h->grads_clean[which] = true;
 }
 
@@ -911,17 +917,29 @@ static void refresh_folded(tvc_sac* h, hipStream_t st) {
 
 // Adam step counters (critics, actor) live on the device so that a captured update keeps counting; these two calls
 // synchronise and are meant for checkpoints only
+static int set_clocks(tvc_sac* h, const int32_t steps[2]) {
+    AdamClock c[2];
+    for (int i = 0; i < 2; ++i) {
+        c[i].step = steps[i]; c[i].done = 0u;
+        c[i].b1t = pow((double)h->cfg.adam_b1, (double)steps[i]);
+        c[i].b2t = pow((double)h->cfg.adam_b2, (double)steps[i]);
+    }
+    TVC_HIP_CHECK(hipMemcpy(h->clk, c, sizeof(c), hipMemcpyHostToDevice));
+    return 0;
+}
 int tvc_sac_get_adam_steps(tvc_sac* h, int32_t out[2]) {
     if (!h || !out) return tvc::set_error(TVC_EINVAL, "null argument");
     TVC_HIP_CHECK(hipSetDevice(h->device));
-    TVC_HIP_CHECK(hipMemcpy(out, h->step, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    AdamClock c[2];
+    TVC_HIP_CHECK(hipMemcpy(c, h->clk, sizeof(c), hipMemcpyDeviceToHost));
+    out[0] = c[0].step; out[1] = c[1].step;
     return 0;
 }
 int tvc_sac_set_adam_steps(tvc_sac* h, const int32_t in[2]) {
     if (!h || !in) return tvc::set_error(TVC_EINVAL, "null argument");
+    if (in[0] < 0 || in[1] < 0) return tvc::set_error(TVC_EINVAL, "negative step count");
     TVC_HIP_CHECK(hipSetDevice(h->device));
-    TVC_HIP_CHECK(hipMemcpy(h->step, in, 2 * sizeof(int), hipMemcpyHostToDevice));
-    return 0;
+    return set_clocks(h, in);
 }
 
 int tvc_sac_sync_derived(tvc_sac* h, void* stream) {
