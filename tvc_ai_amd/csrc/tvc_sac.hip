@@ -4,6 +4,7 @@
 // Replaces MultiAlgorithmAgent._create_sac_agent / get_action (policy part) / update / _update_sac /
 // PhysicsInformedLoss, agent/multi_algorithm_agent.py:587-627, 736-809, 868-912, 950-1016, 236-285.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -171,7 +172,10 @@ struct Ctx {
     std::vector<long> gY;                       // group stride (elements) per buffer
 };
 
-constexpr int kFuseLnMinRows = 1024;  // acting batches at least this large use the fused Linear+LayerNorm kernel
+static int fuse_ln_min_rows() {  // acting batches at least this large use the fused Linear+LayerNorm kernel
+    static const int v = [] { const char* e = getenv("TVC_FUSE_LN_MIN_ROWS"); return e ? atoi(e) : 6144; }();
+    return v;
+}
 static int g_force_variant = 0;  // diagnostics: 0 auto, 1 = 64x64 LDS-tiled, 3 = skinny split-K
 
 static void launch_gemm(bool a_kc, bool b_kc, const GemmArgs& g, int G, hipStream_t st) {
@@ -252,7 +256,7 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
         }
         // acting pass (nothing saved, many rows): Linear (+act, +residual) and the LayerNorm(s) behind it in ONE launch,
         // 32 complete rows per workgroup
-        if (o.type == OP_LINEAR && !save && G == 1 && M >= kFuseLnMinRows && !o.rowtab && (o.in_dim % GBK) == 0 &&
+        if (o.type == OP_LINEAR && !save && G == 1 && M >= fuse_ln_min_rows() && !o.rowtab && (o.in_dim % GBK) == 0 &&
             (o.out_dim == 256 || o.out_dim == 512) && i + 1 < (int)nd.ops.size() && nd.ops[i + 1].type == OP_LN &&
             nd.ops[i + 1].src == out && nd.last_use[out] == i + 1 && g_force_variant == 0) {
             const Op& ln = nd.ops[i + 1];
@@ -534,28 +538,36 @@ __global__ void __launch_bounds__(256) update_prep_kernel(const float* __restric
 // torch.optim.Adam defaults written out (agent/...:623-625): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps); g is pre-scaled by gscale (1 / world size).
 // The step counter t and the running powers b1^t, b2^t (double) live on the device, so a captured update keeps
-// counting: every workgroup reads them, the LAST one to finish advances them.  The gradient is zeroed once consumed,
-// so the next update needs no memset launch.
-struct AdamClock { double b1t, b2t; int step; unsigned done; };
+// counting; a one-thread kernel advances them and stores the two bias-correction factors of the step.
+// The gradient is zeroed once consumed, so the next update needs no memset launch.
+struct AdamClock { double b1t, b2t; int step; float bc1, bc2s; };
+__global__ void adam_tick_kernel(AdamClock* clk, float b1, float b2) {
+    const double b1t = clk->b1t * (double)b1, b2t = clk->b2t * (double)b2;
+    clk->b1t = b1t; clk->b2t = b2t; clk->step += 1;
+    clk->bc1 = (float)(1.0 - b1t);
+    clk->bc2s = (float)sqrt(1.0 - b2t);
+}
 __global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                       AdamClock* clk, float gscale) {
-    const double b1t = clk->b1t * (double)b1, b2t = clk->b2t * (double)b2;  // b^t for this step (uniform)
-    const float bc1 = (float)(1.0 - b1t), bc2s = (float)sqrt(1.0 - b2t);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float gi = g[i] * gscale;
-        const float mi = b1 * m[i] + (1.0f - b1) * gi;
-        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2s + eps);
-        g[i] = 0.0f;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(&clk->done, 1u) == gridDim.x - 1) {
-            clk->b1t = b1t; clk->b2t = b2t; clk->step += 1; clk->done = 0u;
+                                                       const AdamClock* __restrict__ clk, float gscale) {
+    const float bc1 = clk->bc1, bc2s = clk->bc2s;
+    const long n4 = n >> 2;  // all four arrays are 16-byte aligned (asserted at create); n is a multiple of 4
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 g4 = reinterpret_cast<float4*>(g)[i], m4 = reinterpret_cast<float4*>(m)[i];
+        float4 v4 = reinterpret_cast<float4*>(v)[i], p4 = reinterpret_cast<float4*>(p)[i];
+        float* gp = &g4.x; float* mp = &m4.x; float* vp = &v4.x; float* pp = &p4.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gi = gp[j] * gscale;
+            const float mi = b1 * mp[j] + (1.0f - b1) * gi;
+            const float vi = b2 * vp[j] + (1.0f - b2) * gi * gi;
+            mp[j] = mi; vp[j] = vi;
+            pp[j] -= (lr / bc1) * mi / (sqrtf(vi) / bc2s + eps);
         }
+        reinterpret_cast<float4*>(m)[i] = m4;
+        reinterpret_cast<float4*>(v)[i] = v4;
+        reinterpret_cast<float4*>(p)[i] = p4;
+        reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -694,8 +706,9 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     *out = nullptr;
     if (int e = validate(cfg)) return e;
     if (!params || !grads || !adam_m || !adam_v) return tvc::set_error(TVC_EINVAL, "params/grads/adam buffers must be non-NULL");
-    if ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads)) & 15)
-        return tvc::set_error(TVC_EINVAL, "params/grads must be 16-byte aligned");
+    if ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(adam_m) |
+         reinterpret_cast<uintptr_t>(adam_v)) & 15)
+        return tvc::set_error(TVC_EINVAL, "params/grads/adam buffers must be 16-byte aligned");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return tvc::set_error(TVC_ENODEV, "no HIP device visible: libtvc_hip has no CPU fallback");
@@ -758,7 +771,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
         }
     }
     {
-        AdamClock c0[2] = {{1.0, 1.0, 0, 0u}, {1.0, 1.0, 0, 0u}};
+        AdamClock c0[2] = {{1.0, 1.0, 0, 0.f, 0.f}, {1.0, 1.0, 0, 0.f, 0.f}};
         he = hipMemcpy(h->clk, c0, sizeof(c0), hipMemcpyHostToDevice);
         if (he != hipSuccess) {
             (void)hipFree(h->slab);
@@ -849,7 +862,8 @@ int tvc_sac_critic_grads(tvc_sac* h, const float* s, const float* a, const float
 
 static void adam_apply(tvc_sac* h, float* p, float* g, long off, long n, int which, float gscale, hipStream_t st) {
     const tvc_sac_cfg& c = h->cfg;
-    const int blocks = (int)std::min<long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, h->clk + which, c.adam_b1, c.adam_b2);
+    const int blocks = (int)std::min<long>((n / 4 + 255) / 256, 2048);
     hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, st, p, g, h->adam_m + off, h->adam_v + off, n, c.lr, c.adam_b1,
                        c.adam_b2, c.adam_eps, h->clk + which, gscale);
     h->grads_clean[which] = true;
@@ -920,7 +934,7 @@ static void refresh_folded(tvc_sac* h, hipStream_t st) {
 static int set_clocks(tvc_sac* h, const int32_t steps[2]) {
     AdamClock c[2];
     for (int i = 0; i < 2; ++i) {
-        c[i].step = steps[i]; c[i].done = 0u;
+        c[i].step = steps[i]; c[i].bc1 = 0.f; c[i].bc2s = 0.f;
         c[i].b1t = pow((double)h->cfg.adam_b1, (double)steps[i]);
         c[i].b2t = pow((double)h->cfg.adam_b2, (double)steps[i]);
     }

@@ -31,6 +31,7 @@ class VecTrainer:
         self.sync = GradSync() if world > 1 else None
         self.overlap = overlap
         self._side = torch.cuda.Stream(self.device)
+        self._fork = torch.cuda.Event()
         # intrinsic curiosity bonus of the reference's training env (scripts/train.py:318, env/...:496-502)
         self.curiosity = None
         if enable_curiosity:
@@ -102,7 +103,11 @@ class VecTrainer:
         self.eps2.normal_()
         s, a, r, s2, d = self.batch
         gs = self.sync.grad_scale if self.sync is not None else 1.0
-        side.wait_stream(main)
+        self._fork.record(main)
+        # the acting pass is enqueued FIRST: the host needs hundreds of microseconds to enqueue the ~100 learner launches,
+        # and the GPU would otherwise sit idle on the main stream for that long at small env counts
+        self.collect()
+        side.wait_event(self._fork)
         with torch.cuda.stream(side):
             sac.critic_grads(s, a, r, s2, d, self.eps1)
             if self.sync is not None:
@@ -111,7 +116,6 @@ class VecTrainer:
             sac.actor_grads(s, self.eps2)
             if self.sync is not None:
                 self.sync(sac.grads[:sac.n_policy])
-        self.collect()
         main.wait_stream(side)
         sac.actor_apply(gs)
 
