@@ -390,7 +390,7 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
             flops = 4.88e9 if args.family == 0 else 0.565e9  # SURVEY 8d algorithmic minimum per update
             rep["sac_learner_only"] = {"updates_per_s": 1e6 / us_up, "us_per_update": us_up, "batch": B,
                                        "mfma_tflops": flops / (us_up * 1e-6) / 1e12,
-                                       "note": "latency-bound at batch 256 (H5): ~170 dependent launches per update"}
+                                       "note": "latency-bound at batch 256 (H5): ~100 dependent launches per update"}
             sac.close()
         except Exception as e:
             rep["sac_learner_only"] = {"error": str(e)}
