@@ -394,6 +394,19 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
             sac.close()
         except Exception as e:
             rep["sac_learner_only"] = {"error": str(e)}
+        # the reference's default acting path (hierarchical_rl.enabled, agent/...:751-754) for all N envs per call
+        try:
+            from tvc_ai_amd.hierarchical import HierarchicalPolicy
+            hp = HierarchicalPolicy(10, 2, device=device, max_rows=n, seed=3)
+            ob = torch.randn(n, 10, device=device)
+            ep, uu = torch.randn(n, 2, device=device), torch.rand(n, device=device)
+            us_h = graph_time_us(lambda k: hp.act(ob, ep, uu), 5, device)
+            rep["hierarchical_acting"] = {"rows_per_s": n / (us_h * 1e-6), "us_per_call": us_h, "rows": n,
+                                          "note": "goal policy + categorical draw + goal-conditioned low-level policy (with SE block)"}
+            hp.close()
+            del ob, ep, uu
+        except Exception as e:
+            rep["hierarchical_acting"] = {"error": str(e)}
         # BASELINE configs[0] through the drop-in surface: ONE env (EnhancedRocketTVCEnv wrapper) + MultiAlgorithmAgent,
         # the loop of scripts/train.py:535-620 (get_action -> step -> B=1 update with a BoolTensor `dones`), numpy in/out
         try:
@@ -401,7 +414,8 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
             from tvc_ai_amd.agent import MultiAlgorithmAgent
             env1 = EnhancedRocketTVCEnv(enable_curiosity=True, device=device)
             ag = MultiAlgorithmAgent(10, 2, {"tvc_native": {"batch_size": 1, "max_act_rows": 16},
-                                             "physics_informed": {"enabled": True}}, device=device)
+                                             "physics_informed": {"enabled": True}, "hierarchical_rl": {"enabled": True},
+                                             "safety": {"safety_layer": {"enabled": True}}}, device=device)
             obs, _ = env1.reset()
             n1 = 0
             t0 = time.perf_counter()
@@ -414,6 +428,7 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
                 obs = env1.reset()[0] if (term or trunc) else nobs
                 n1 += 1
             rep["reference_plumbing_n1"] = {"steps_per_s": n1 / (time.perf_counter() - t0), "steps": n1,
+                                            "config": "config.yaml defaults: hierarchical goal policy + safety layer + curiosity + physics-informed loss on",
                                             "note": "1 env + 1 online SAC update per step through the reference's Python surface "
                                                     "(host round trips every call); reference docs imply 35-93 steps/s (BASELINE.md)"}
             env1.close()

@@ -168,7 +168,8 @@ typedef struct tvc_sac_cfg {
                                        batch-row-indexed table, row index taken modulo pe_rows */
     float gamma, alpha, tau, lr;    /* 0.99, 0.2, 0.005, 3e-4  (agent/...:971,998,1005,623-625) */
     float adam_b1, adam_b2, adam_eps; /* torch.optim.Adam defaults */
-    int32_t _pad;
+    int32_t use_se;                 /* 1: SqueezeExcitation(d_model, 16) after feature_norm (agent/...:104-118,151-152,214-215): the
+                                       NetworkConfig() default of the hierarchical low-level policy; acting only */
 } tvc_sac_cfg;
 
 void tvc_sac_default_cfg(tvc_sac_cfg* cfg, int32_t family);
@@ -245,6 +246,13 @@ typedef struct tvc_mlp tvc_mlp;
  * then bias), every tensor 16-byte aligned; tvc_mlp_param_count floats in total (host-only queries). */
 int64_t tvc_mlp_param_count(const int32_t* dims, int32_t n_layers);
 int tvc_mlp_tensor_offset(const int32_t* dims, int32_t n_layers, int32_t layer, int64_t* w_off, int64_t* b_off);
+/* act may carry TVC_MLP_LAYERNORM: a LayerNorm (eps 1e-5) behind every hidden activation, i.e. Linear-act-LN-...-Linear, the
+ * shape of HierarchicalAgent.high_level_policy (agent/multi_algorithm_agent.py:366-374).  tvc_mlp_layout is the
+ * parameter table for that case: offsets of layer `layer` (weight, bias, LayerNorm gamma / beta or -1), returns the total
+ * float count (layer = -1: count only), -1 on error. */
+#define TVC_MLP_LAYERNORM 0x100
+int64_t tvc_mlp_layout(const int32_t* dims, int32_t n_layers, int32_t act_flags, int32_t layer, int64_t* w_off, int64_t* b_off,
+                       int64_t* ln_w_off, int64_t* ln_b_off);
 int tvc_mlp_create(const int32_t* dims, int32_t n_layers, int32_t act, int32_t max_rows, int32_t device,
                    const float* params_dev, tvc_mlp** out);
 void tvc_mlp_destroy(tvc_mlp* mlp);
@@ -261,6 +269,12 @@ int tvc_curiosity_add(tvc_mlp* mlp, const float* prev_obs, int32_t obs_ld, const
  * correction net in `mlp` (state_dim+A -> ... -> A): out = clamp(violates ? net([state | proposed]) : proposed). */
 int tvc_safety_apply(tvc_mlp* mlp, const float* state, int32_t state_dim, const float* proposed, float* out, int32_t n,
                      float max_tilt, float max_angular_velocity, float max_control_effort, void* stream);
+
+/* HierarchicalAgent.select_goal + the input of its low-level policy (agent/multi_algorithm_agent.py:396-413): softmax over
+ * logits[n, n_goals], one categorical draw per row from the uniform u[n] in [0,1) (torch.multinomial's role), then
+ * state_goal_out[n, state_dim + n_goals] = [state[:, :state_dim] | one_hot(goal)]; goal_idx_out int32[n] or NULL. */
+int tvc_goal_sample(const float* logits, const float* u, const float* state, int32_t state_ld, int32_t state_dim,
+                    int32_t n_goals, int32_t n, float* state_goal_out, int32_t* goal_idx_out, void* stream);
 
 /* ------------------------------------------------------------------ replay buffer (K8) */
 

@@ -53,6 +53,9 @@ def actor_forward(P, obs, batch_pe=False, n_layers=4):
         f = f @ P[pre + "linear2.weight"].T + P[pre + "linear2.bias"]
         x = _ln(x + f, P, pre + "norm2")
     x = _ln(x, P, "feature_norm")
+    if "se_block.fc1.weight" in P:  # SqueezeExcitation (agent/...:104-118): pooling a [B, C, 1] tensor over its last axis is the identity
+        y = F.relu(x @ P["se_block.fc1.weight"].T + P["se_block.fc1.bias"])
+        x = x * torch.sigmoid(y @ P["se_block.fc2.weight"].T + P["se_block.fc2.bias"])
     h = _ln(F.gelu(x @ P["policy_head.0.weight"].T + P["policy_head.0.bias"]), P, "policy_head.2")
     h = _ln(F.gelu(h @ P["policy_head.4.weight"].T + P["policy_head.4.bias"]), P, "policy_head.6")
     out = h @ P["policy_head.8.weight"].T + P["policy_head.8.bias"]
@@ -184,3 +187,24 @@ def safety_layer(S, state, proposed, max_tilt=0.52, max_w=5.0, max_effort=1.0):
     corr = h @ S["4.weight"].T + S["4.bias"]
     out = torch.where(viol.unsqueeze(1), corr, proposed)
     return torch.clamp(out, -1.0, 1.0), viol
+
+
+def goal_logits(H, state):
+    """HierarchicalAgent.high_level_policy (agent/multi_algorithm_agent.py:366-374): Linear-GELU-LN-Linear-GELU-LN-Linear."""
+    h = _ln(F.gelu(state @ H["0.weight"].T + H["0.bias"]), H, "2")
+    h = _ln(F.gelu(h @ H["3.weight"].T + H["3.bias"]), H, "5")
+    return h @ H["6.weight"].T + H["6.bias"]
+
+
+def goal_from_uniform(logits, u):
+    """categorical draw by inverse CDF over softmax(logits) with u in [0,1): the role of torch.multinomial in select_goal (:396-402)"""
+    p = torch.softmax(logits, dim=-1)
+    cdf = torch.cumsum(p, dim=-1)
+    return torch.clamp((u.unsqueeze(1) >= cdf).sum(dim=1), max=logits.shape[1] - 1)
+
+
+def hierarchical_act(H, Plow, state, goal_idx, batch_pe=False):
+    """HierarchicalAgent.get_action (:404-417): low-level policy on [state | one_hot(goal)] -> mean, log_std"""
+    onehot = F.one_hot(goal_idx.long(), num_classes=H["6.weight"].shape[0]).to(state)
+    return actor_forward(Plow, torch.cat([state, onehot], dim=-1), batch_pe=batch_pe)
+

@@ -65,7 +65,7 @@ class SacCfg(C.Structure):
         ("mlp1", C.c_int32), ("mlp2", C.c_int32), ("critic1", C.c_int32), ("critic2", C.c_int32),
         ("batch_size", C.c_int32), ("max_act_rows", C.c_int32), ("pe_rows", C.c_int32),
         ("gamma", C.c_float), ("alpha", C.c_float), ("tau", C.c_float), ("lr", C.c_float),
-        ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("_pad", C.c_int32),
+        ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("use_se", C.c_int32),
     ]
 
 
@@ -84,6 +84,9 @@ SIGNATURES.update({
     "tvc_sac_act": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, C.c_int32, _VP]),
     "tvc_mlp_param_count": (C.c_int64, [C.POINTER(C.c_int32), C.c_int32]),
     "tvc_mlp_tensor_offset": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "tvc_mlp_layout": (C.c_int64, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "tvc_goal_sample": (C.c_int, [_VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, _VP, _VP]),
     "tvc_mlp_create": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, C.POINTER(_VP)]),
     "tvc_mlp_destroy": (None, [_VP]),
     "tvc_mlp_forward": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, _VP, C.c_int32, C.c_int32, _VP, _VP]),

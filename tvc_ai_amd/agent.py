@@ -342,8 +342,11 @@ class MultiAlgorithmAgent:
 
     Same constructor ``(obs_dim, action_dim, config)`` and methods ``select_algorithm``, ``get_action``,
     ``update``, ``update_performance``, ``save_checkpoint``, ``load_checkpoint``, ``to``; attributes
-    ``performance_history``, ``algorithms``, ``device``.  PPO / TD3 / ensemble / hierarchical paths are out of
-    scope: ``select_algorithm`` answers 'sac'.  Deliberate fix: ``update`` accepts
+    ``performance_history``, ``algorithms``, ``device``.  PPO / TD3 / ensemble paths are out of scope (SURVEY
+    section 2): ``select_algorithm`` answers 'sac'.  With ``hierarchical_rl.enabled`` (true in the shipped
+    config.yaml:103-104) ``get_action`` follows the reference (:751-754) and acts with the never-trained goal policy +
+    goal-conditioned low-level policy of ``hierarchical.HierarchicalPolicy`` instead of the SAC policy; set it to false
+    to act with the policy that ``update`` trains.  Deliberate fix: ``update`` accepts
     the BoolTensor ``dones`` that scripts/train.py:582 builds (the reference raises on it and skips the update).
     """
 
@@ -378,6 +381,13 @@ class MultiAlgorithmAgent:
                                             state_dim=obs_dim, action_dim=action_dim, max_tilt=cons.get("max_tilt", 0.52),
                                             max_angular_velocity=cons.get("max_angular_velocity", 5.0), seed=seed)
 
+        # HierarchicalAgent (agent/...:499-504): acting goes through it when enabled
+        self.hierarchical_agent = None
+        if (self.config.get("hierarchical_rl", {}) or {}).get("enabled", False):
+            from .hierarchical import HierarchicalPolicy
+            self.hierarchical_agent = HierarchicalPolicy(obs_dim, action_dim, device=self.device,
+                                                         max_rows=int(native.get("max_act_rows", 4096)), seed=seed)
+
     def to(self, device):
         if torch.device(device) != self.device:
             self.logger.warning("MultiAlgorithmAgent(native) stays on %s (requested %s)", self.device, device)
@@ -395,10 +405,16 @@ class MultiAlgorithmAgent:
                 state = state.unsqueeze(0)
             state = state.contiguous()
             eps = None if deterministic else torch.randn((state.shape[0], self.action_dim), device=self.device, generator=self._gen)
-            act, mean, ls = self.sac.act(state, eps, clamp=self.safety_layer is None)
+            goal = None
+            if self.hierarchical_agent is not None:  # agent/...:751-754
+                act, mean, ls, goal = self.hierarchical_agent.act(state, eps, clamp=self.safety_layer is None)
+            else:
+                act, mean, ls = self.sac.act(state, eps, clamp=self.safety_layer is None)
             if self.safety_layer is not None:  # sees the raw sample, then the result is clamped (agent/...:785-789)
                 act = self.safety_layer.apply(state, act)
             info = {"algorithm": "sac", "mean": mean.cpu().numpy(), "log_std": ls.cpu().numpy(), "value": None}
+            if goal is not None:
+                info["goal"] = goal.cpu().numpy()
             return act.cpu().numpy(), info
         except Exception as e:  # reference convention: log and fall back to a random action (agent/...:804-809)
             self.logger.error(f"Error in get_action: {e}")

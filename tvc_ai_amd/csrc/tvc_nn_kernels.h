@@ -14,14 +14,14 @@ namespace tvcnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };  // sigmoid: forward only (SE gate)
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float gelu_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.7071067811865476f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 __device__ __forceinline__ float act_f(float x, int act) {
-    return act == ACT_GELU ? gelu_f(x) : (act == ACT_RELU ? fmaxf(x, 0.0f) : x);
+    return act == ACT_GELU ? gelu_f(x) : (act == ACT_RELU ? fmaxf(x, 0.0f) : (act == ACT_SIGMOID ? 1.0f / (1.0f + expf(-x)) : x));
 }
 __device__ __forceinline__ float act_grad(float z, int act) {
     return act == ACT_GELU ? gelu_grad(z) : (act == ACT_RELU ? (z > 0.0f ? 1.0f : 0.0f) : 1.0f);
@@ -552,7 +552,8 @@ struct ThinArgs {
     int ldx, ldx2;
     const float* W; const float* bias; // W[N, K], bias[N]
     const float* rowtab; int rowtab_rows;
-    float* Y; float* Z;                // forward: Y = act(Z), Z optional (pre-activation for backward)
+    float* Y; float* Z;                // forward: Y = act(Z) (* Mul), Z optional (pre-activation for backward)
+    const float* Mul;                  // optional [M, N] gate input multiplied in (SqueezeExcitation: x * sigmoid(fc2(.)))
     const float* dZ; float* dW; float* dX;
     int M, N, K, K1, act;
     long gX, gX2, gW, gB, gY, gDW, gDX;  // group strides (blockIdx.z)
@@ -596,7 +597,9 @@ __global__ void __launch_bounds__(256) thin_fwd_kernel(ThinArgs a) {
         if (a.rowtab) v += a.rowtab[(long)(row % a.rowtab_rows) * a.N + n];
         const long o = (long)row * a.N + n;
         if (Z) Z[o] = v;
-        Y[o] = act_f(v, a.act);
+        v = act_f(v, a.act);
+        if (a.Mul) v *= a.Mul[z * a.gY + o];
+        Y[o] = v;
     }
 }
 // dW[n, k] = sum_m dZ[m, n] X[m, k]: 32 weight rows per workgroup, the 8 half-waves split the batch rows
@@ -729,6 +732,46 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(LnArgs a) {
         o.z = (v[i + 2] - mean) * rstd * gg.z + bb.z;
         o.w = (v[i + 3] - mean) * rstd * gg.w + bb.w;
         *reinterpret_cast<float4*>(y + c) = o;
+    }
+    if (lane == 0 && a.mean) {
+        a.mean[z * a.gS + row] = mean;
+        a.rstd[z * a.gS + row] = rstd;
+    }
+}
+
+// any width up to 1024 (inference helpers: the 128-wide norm of the hierarchical goal policy): strided columns per lane
+__global__ void __launch_bounds__(256) layernorm_fwd_any_kernel(LnArgs a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.M) return;
+    const long z = blockIdx.y;
+    const float* x = a.X + z * a.gX + (long)row * a.N;
+    float v[16];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i;
+        const float t = x[min(c, a.N - 1)];
+        v[i] = c < a.N ? t : 0.0f;
+        s += v[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)a.N;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float d = (lane + 64 * i) < a.N ? v[i] - mean : 0.0f;
+        q += d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)a.N + 1e-5f);
+    float* y = a.Y + z * a.gY + (long)row * a.N;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = lane + 64 * i, cc = min(c, a.N - 1);
+        const float o = (v[i] - mean) * rstd * a.gamma[z * a.gP + cc] + a.beta[z * a.gP + cc];
+        if (c < a.N) y[c] = o;
     }
     if (lane == 0 && a.mean) {
         a.mean[z * a.gS + row] = mean;

@@ -22,6 +22,7 @@ enum { OP_LINEAR = 0, OP_LN = 1, OP_HEAD = 2 };
 struct Op {
     int type, in_dim, out_dim, act, src, res, rowtab;
     int ext = 0;  // 1: weight/bias offsets address the derived-weights buffer (folded W_o W_v of the acting net)
+    int mul = -1;  // buffer multiplied into the output after the activation (SqueezeExcitation gate); thin layers only
     long w, b;  // offsets inside the net's parameter block (LINEAR/HEAD: weight[out,in], bias[out]; LN: gamma, beta)
 };
 struct TensorInfo { std::string name; long off; int rows, cols; };
@@ -57,6 +58,7 @@ struct NetDef {
             producer[i + 1] = i;
             last_use[ops[i].src] = i;
             if (ops[i].res >= 0) { res_consumer[ops[i].res] = i; last_use[ops[i].res] = i; }
+            if (ops[i].mul >= 0) last_use[ops[i].mul] = i;
         }
         last_use[nb - 1] = (int)ops.size();
     }
@@ -78,6 +80,12 @@ static NetDef build_actor(const tvc_sac_cfg& c) {
             x = n.add(OP_LN, p + "norm2", d, d, 0, g, -1, 0);
         }
         x = n.add(OP_LN, "feature_norm", d, d, 0, x, -1, 0);
+        if (c.use_se) {  // SqueezeExcitation(d, reduction 16) of agent/...:104-118: x * sigmoid(fc2(relu(fc1(x)))); inference only
+            const int y = n.add(OP_LINEAR, "se_block.fc1", d, d / 16, ACT_RELU, x, -1, 0);
+            const int g = n.add(OP_LINEAR, "se_block.fc2", d / 16, d, ACT_SIGMOID, y, -1, 0);
+            n.ops.back().mul = x;
+            x = g;
+        }
         x = n.add(OP_LINEAR, "policy_head.0", d, c.head1, ACT_GELU, x, -1, 0);
         x = n.add(OP_LN, "policy_head.2", c.head1, c.head1, 0, x, -1, 0);
         x = n.add(OP_LINEAR, "policy_head.4", c.head1, c.head2, ACT_GELU, x, -1, 0);
@@ -120,6 +128,7 @@ static NetDef derive_infer(const NetDef& a, FoldInfo& fi) {
             Op c = op;
             c.src = map[op.src];
             c.res = op.res >= 0 ? map[op.res] : -1;
+            c.mul = op.mul >= 0 ? map[op.mul] : -1;
             n.ops.push_back(c);
             map[i + 1] = (int)n.ops.size();
         }
@@ -162,6 +171,8 @@ static int validate(const tvc_sac_cfg* c) {
     }
     if (c->batch_size < 1 || c->max_act_rows < 1) return tvc::set_error(TVC_EINVAL, "batch_size / max_act_rows must be >= 1");
     if (c->pe_rows < 1) return tvc::set_error(TVC_EINVAL, "pe_rows must be >= 1");
+    if (c->use_se != 0 && c->use_se != 1) return tvc::set_error(TVC_EINVAL, "use_se must be 0 or 1");
+    if (c->use_se && (c->family != 0 || c->d_model != 256)) return tvc::set_error(TVC_EINVAL, "use_se needs family 0, d_model 256");
     return 0;
 }
 
@@ -230,12 +241,13 @@ static void launch_gemm_bwd_pair(const GemmArgs& w, const GemmArgs& x, int G, hi
 struct In2 { const float* X2; long gX2; int K1, ldx, ldx2; };
 static ThinArgs thin_input(const Op& o, const float* X, long gX, const In2* in2, int M) {
     ThinArgs a{};
+    if (o.src != 0) in2 = nullptr;  // only the net input can be a two-source concatenation
     a.X = X; a.gX = gX; a.K = o.in_dim; a.M = M; a.N = o.out_dim;
     a.K1 = in2 ? in2->K1 : o.in_dim; a.ldx = in2 ? in2->ldx : o.in_dim;
     a.X2 = in2 ? in2->X2 : nullptr; a.ldx2 = in2 ? in2->ldx2 : 0; a.gX2 = in2 ? in2->gX2 : 0;
     return a;
 }
-static bool thin_ok(const Op& o) { return o.type == OP_LINEAR && o.src == 0 && o.in_dim <= THIN_K && o.res < 0; }
+static bool thin_ok(const Op& o) { return o.type == OP_LINEAR && o.in_dim <= THIN_K && o.res < 0; }
 
 // forward of one net (G parameter groups batched through blockIdx.z).  X: [G?][M,in]; gX = 0 shares one input.
 static void net_forward(const NetDef& nd, const float* P, long gP, const float* X, long gX, int M, int G, Ctx& c, bool save,
@@ -246,9 +258,10 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
         const float* in = o.src == 0 ? X : c.Y[o.src];
         const long gin = o.src == 0 ? gX : c.gY[o.src];
         if (thin_ok(o) && g_force_variant == 0) {  // input layer (in_dim <= 16): plain-FMA kernel, reads [X | X2] in place
-            ThinArgs a = thin_input(o, X, gX, in2, M);
+            ThinArgs a = thin_input(o, in, gin, in2, M);
             a.W = P + o.w; a.bias = P + o.b; a.gW = gP; a.gB = gP;
             if (o.rowtab && pe) { a.rowtab = pe; a.rowtab_rows = pe_rows; }
+            if (o.mul >= 0) a.Mul = c.Y[o.mul];
             a.Y = c.Y[out]; a.gY = c.gY[out]; a.act = o.act;
             a.Z = (save && o.act != ACT_NONE) ? c.Z[out] : nullptr;
             hipLaunchKernelGGL(thin_fwd_kernel, dim3((M + THIN_ROWS - 1) / THIN_ROWS, (o.out_dim + 255) / 256, G), dim3(256), 0, st, a);
@@ -294,7 +307,8 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
             a.M = M; a.N = o.out_dim; a.gX = gin; a.gY = c.gY[out]; a.gP = gP; a.gS = M;
             dim3 grid((M + 3) / 4, G), block(256);
             if (o.out_dim == 256) hipLaunchKernelGGL((layernorm_fwd_kernel<4>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((layernorm_fwd_kernel<8>), grid, block, 0, st, a);
+            else if (o.out_dim == 512) hipLaunchKernelGGL((layernorm_fwd_kernel<8>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL(layernorm_fwd_any_kernel, grid, block, 0, st, a);
         } else {
             HeadArgs a{};
             a.X = in; a.W = P + o.w; a.b = P + o.b; a.out = c.Y[out];
@@ -368,7 +382,7 @@ static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, l
             else hipLaunchKernelGGL((layernorm_bwd_kernel<8>), grid, block, 0, st, a);
         } else {  // LINEAR: c.dY[out] already holds dZ (act' and bias column sums were fused by its writer)
             const float* dZ = c.dY[out];
-            if (thin_ok(o) && g_force_variant == 0) {
+            if (thin_ok(o) && o.src == 0 && g_force_variant == 0) {
                 ThinArgs a = thin_input(o, X, gX, in2, M);
                 a.dZ = dZ; a.gY = c.gY[out];
                 if (Gr) {
@@ -828,6 +842,7 @@ static int check_batch_ptrs(const void* a, const void* b, const void* c) {
 int tvc_sac_critic_grads(tvc_sac* h, const float* s, const float* a, const float* r, const float* s2, const float* d,
                          const float* eps_next, float* losses, void* stream) {
     if (!h || !losses) return tvc::set_error(TVC_EINVAL, "null argument");
+    if (h->cfg.use_se) return tvc::set_error(TVC_EINVAL, "use_se nets are acting-only (the reference never trains its hierarchical policy)");
     if (check_batch_ptrs(s, a, r) || check_batch_ptrs(s2, d, eps_next)) return TVC_EINVAL;
     TVC_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
@@ -879,6 +894,7 @@ int tvc_sac_critic_apply(tvc_sac* h, float grad_scale, void* stream) {
 
 int tvc_sac_actor_grads(tvc_sac* h, const float* s, const float* eps_new, float* losses, void* stream) {
     if (!h || !s || !eps_new || !losses) return tvc::set_error(TVC_EINVAL, "null argument");
+    if (h->cfg.use_se) return tvc::set_error(TVC_EINVAL, "use_se nets are acting-only (the reference never trains its hierarchical policy)");
     TVC_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const tvc_sac_cfg& c = h->cfg;
@@ -1026,15 +1042,21 @@ struct tvc_mlp {
 };
 
 namespace {
-static NetDef build_mlp(const int32_t* dims, int n_layers, int act) {
+// act_flags: low byte = hidden activation, TVC_MLP_LAYERNORM (0x100) = a LayerNorm behind every hidden activation
+// (nn.Sequential numbering Linear, act, LayerNorm, Linear, ...: the goal policy of agent/...:366-374)
+static NetDef build_mlp(const int32_t* dims, int n_layers, int act_flags) {
     NetDef n;
     n.in_dim = dims[0];
+    const int act = act_flags & 0xff;
+    const bool ln = (act_flags & TVC_MLP_LAYERNORM) != 0;
+    const int per = ln ? 3 : 2;
     int x = 0;
     for (int l = 0; l < n_layers; ++l) {
         const bool last = l == n_layers - 1;
-        const std::string name = std::to_string(2 * l);  // nn.Sequential numbering: Linear, act, Linear, ...
+        const std::string name = std::to_string(per * l);
         if (last && dims[l + 1] <= 4 && (dims[l] % 4) == 0) x = n.add(OP_HEAD, name, dims[l], dims[l + 1], 0, x, -1, 0);
         else x = n.add(OP_LINEAR, name, dims[l], dims[l + 1], last ? ACT_NONE : act, x, -1, 0);
+        if (ln && !last) x = n.add(OP_LN, std::to_string(per * l + 2), dims[l + 1], dims[l + 1], 0, x, -1, 0);
     }
     n.finish();
     return n;
@@ -1044,6 +1066,38 @@ static int mlp_dims_ok(const int32_t* dims, int n_layers) {
     for (int l = 0; l <= n_layers; ++l)
         if (dims[l] < 1 || dims[l] > 4096) return tvc::set_error(TVC_EINVAL, "layer width out of range");
     return 0;
+}
+static int mlp_flags_ok(const int32_t* dims, int n_layers, int act_flags) {
+    const int act = act_flags & 0xff;
+    if (act < ACT_NONE || act > ACT_RELU || (act_flags & ~(0xff | TVC_MLP_LAYERNORM))) return tvc::set_error(TVC_EINVAL, "bad act / flags");
+    if (act_flags & TVC_MLP_LAYERNORM)
+        for (int l = 1; l < n_layers; ++l)
+            if (dims[l] > 1024) return tvc::set_error(TVC_EINVAL, "LayerNorm widths up to 1024");
+    return 0;
+}
+
+// softmax over the goal logits + one categorical draw per row from a uniform u in [0,1) (HierarchicalAgent.select_goal,
+// agent/...:396-402), then the low-level policy's input [state | one-hot(goal)] (:404-413)
+__global__ void goal_sample_kernel(const float* __restrict__ logits, const float* __restrict__ u, const float* __restrict__ state,
+                                   int state_ld, int sd, int ng, int M, float* __restrict__ out, int* __restrict__ idx) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float* lg = logits + (long)m * ng;
+    float mx = lg[0];
+    for (int j = 1; j < ng; ++j) mx = fmaxf(mx, lg[j]);
+    float tot = 0.f;
+    for (int j = 0; j < ng; ++j) tot += expf(lg[j] - mx);
+    const float target = u[m] * tot;
+    float cum = 0.f;
+    int g = ng - 1;
+    for (int j = 0; j < ng; ++j) {
+        cum += expf(lg[j] - mx);
+        if (target < cum) { g = j; break; }
+    }
+    float* o = out + (long)m * (sd + ng);
+    for (int k = 0; k < sd; ++k) o[k] = state[(long)m * state_ld + k];
+    for (int j = 0; j < ng; ++j) o[sd + j] = j == g ? 1.0f : 0.0f;
+    if (idx) idx[m] = g;
 }
 
 // dense [n, k1 + k2] input from the first k1 columns of a (row stride lda) and the first k2 of b (row stride ldb)
@@ -1113,6 +1167,22 @@ int64_t tvc_mlp_param_count(const int32_t* dims, int32_t n_layers) {
     if (mlp_dims_ok(dims, n_layers)) return -1;
     return build_mlp(dims, n_layers, ACT_RELU).n_params;
 }
+int64_t tvc_mlp_layout(const int32_t* dims, int32_t n_layers, int32_t act_flags, int32_t layer, int64_t* w_off, int64_t* b_off,
+                       int64_t* ln_w_off, int64_t* ln_b_off) {
+    if (mlp_dims_ok(dims, n_layers) || mlp_flags_ok(dims, n_layers, act_flags)) return -1;
+    NetDef n = build_mlp(dims, n_layers, act_flags);
+    if (layer >= n_layers) { tvc::set_error(TVC_EINVAL, "layer out of range"); return -1; }
+    if (layer >= 0) {
+        const bool ln = (act_flags & TVC_MLP_LAYERNORM) != 0;
+        const int oi = ln ? 2 * layer : layer;  // hidden layers own two ops (Linear, LayerNorm) when ln
+        if (w_off) *w_off = n.ops[oi].w;
+        if (b_off) *b_off = n.ops[oi].b;
+        const bool has_ln = ln && layer < n_layers - 1;
+        if (ln_w_off) *ln_w_off = has_ln ? n.ops[oi + 1].w : -1;
+        if (ln_b_off) *ln_b_off = has_ln ? n.ops[oi + 1].b : -1;
+    }
+    return n.n_params;
+}
 int tvc_mlp_tensor_offset(const int32_t* dims, int32_t n_layers, int32_t layer, int64_t* w_off, int64_t* b_off) {
     if (int e = mlp_dims_ok(dims, n_layers)) return e;
     if (layer < 0 || layer >= n_layers) return tvc::set_error(TVC_EINVAL, "layer out of range");
@@ -1126,7 +1196,8 @@ int tvc_mlp_create(const int32_t* dims, int32_t n_layers, int32_t act, int32_t m
     if (!out) return tvc::set_error(TVC_EINVAL, "out is NULL");
     *out = nullptr;
     if (int e = mlp_dims_ok(dims, n_layers)) return e;
-    if (!params_dev || max_rows < 1 || act < ACT_NONE || act > ACT_RELU) return tvc::set_error(TVC_EINVAL, "bad argument");
+    if (!params_dev || max_rows < 1) return tvc::set_error(TVC_EINVAL, "bad argument");
+    if (int e = mlp_flags_ok(dims, n_layers, act)) return e;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return tvc::set_error(TVC_ENODEV, "no HIP device visible: libtvc_hip has no CPU fallback");
@@ -1195,6 +1266,15 @@ int tvc_safety_apply(tvc_mlp* h, const float* state, int32_t state_dim, const fl
     const float* corr = mlp_run(h, state, state_dim, state_dim, proposed, A, n, st);
     hipLaunchKernelGGL(safety_select_kernel, dim3((n + 255) / 256), dim3(256), 0, st, state, state_dim, proposed, corr, out, n, A,
                        max_tilt, max_w, max_effort);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int tvc_goal_sample(const float* logits, const float* u, const float* state, int32_t state_ld, int32_t state_dim, int32_t n_goals,
+                    int32_t n, float* state_goal_out, int32_t* goal_idx_out, void* stream) {
+    if (!logits || !u || !state || !state_goal_out) return tvc::set_error(TVC_EINVAL, "null argument");
+    if (n < 1 || n_goals < 1 || n_goals > 64 || state_dim < 1 || state_ld < state_dim) return tvc::set_error(TVC_EINVAL, "bad shape");
+    hipLaunchKernelGGL(goal_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, u, state, state_ld,
+                       state_dim, n_goals, n, state_goal_out, goal_idx_out);
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -1,6 +1,6 @@
 """Acting-path extras of the reference as device kernels (csrc/tvc_sac.hip, tvc_mlp_*):
 
-* ``SmallMLP``      -- dims[0] -> ... -> dims[-1] ReLU MLP handle with torch-owned parameters.
+* ``SmallMLP``      -- dims[0] -> ... -> dims[-1] MLP handle (ReLU / GELU, optional LayerNorms) with torch-owned parameters.
 * ``VecCuriosity``  -- CuriosityModule.compute_intrinsic_reward (env/enhanced_rocket_tvc_env.py:226-269) for N envs:
                        the reference builds the forward model with torch's default init and never trains it.
 * ``SafetyLayer``   -- SafetyLayer.forward (agent/multi_algorithm_agent.py:287-351) + get_action's clamp.
@@ -14,28 +14,38 @@ import torch
 from . import _native as nat
 
 
+MLP_LAYERNORM = 0x100  # TVC_MLP_LAYERNORM of include/tvc_native.h
+
+
 class SmallMLP:
-    def __init__(self, dims: Sequence[int], device="cuda:0", max_rows: int = 4096, act: int = 2, seed: int = 0):
+    """dims[0] -> ... -> dims[-1]; act 1 GELU / 2 ReLU between layers; layernorm=True puts a LayerNorm behind every hidden
+    activation (nn.Sequential numbering Linear, act, LayerNorm, Linear, ...)."""
+
+    def __init__(self, dims: Sequence[int], device="cuda:0", max_rows: int = 4096, act: int = 2, seed: int = 0,
+                 layernorm: bool = False):
         self.L = nat.load()
         self.dims = [int(d) for d in dims]
         self.n_layers = len(self.dims) - 1
+        self.layernorm = bool(layernorm)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise nat.TvcError("SmallMLP needs a GPU device: there is no CPU fallback")
         self._dims_c = (C.c_int32 * len(self.dims))(*self.dims)
-        n = self.L.tvc_mlp_param_count(self._dims_c, self.n_layers)
+        flags = act | (MLP_LAYERNORM if layernorm else 0)
+        n = self.L.tvc_mlp_layout(self._dims_c, self.n_layers, flags, -1, None, None, None, None)
         if n < 0:
-            nat.check(int(n))
+            raise nat.TvcError(self.L.tvc_last_error().decode())
         self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.offsets = []
         for l in range(self.n_layers):
-            w, b = C.c_int64(), C.c_int64()
-            nat.check(self.L.tvc_mlp_tensor_offset(self._dims_c, self.n_layers, l, C.byref(w), C.byref(b)))
-            self.offsets.append((w.value, b.value))
+            w, b, gw, gb = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+            if self.L.tvc_mlp_layout(self._dims_c, self.n_layers, flags, l, C.byref(w), C.byref(b), C.byref(gw), C.byref(gb)) < 0:
+                raise nat.TvcError(self.L.tvc_last_error().decode())
+            self.offsets.append((w.value, b.value, gw.value, gb.value))
         self.max_rows = max_rows
         self._h = C.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        nat.check(self.L.tvc_mlp_create(self._dims_c, self.n_layers, act, max_rows, dev_index, self.params.data_ptr(), C.byref(self._h)))
+        nat.check(self.L.tvc_mlp_create(self._dims_c, self.n_layers, flags, max_rows, dev_index, self.params.data_ptr(), C.byref(self._h)))
         self.init_default(seed)
 
     def weight(self, l):
@@ -45,19 +55,41 @@ class SmallMLP:
     def bias(self, l):
         return self.params[self.offsets[l][1]:self.offsets[l][1] + self.dims[l + 1]]
 
+    def ln_weight(self, l):
+        return self.params[self.offsets[l][2]:self.offsets[l][2] + self.dims[l + 1]]
+
+    def ln_bias(self, l):
+        return self.params[self.offsets[l][3]:self.offsets[l][3] + self.dims[l + 1]]
+
     def init_default(self, seed=0):
-        """torch's default nn.Linear init: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias"""
+        """torch's default nn.Linear init: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and bias; LayerNorm (1, 0)"""
         g = torch.Generator().manual_seed(seed)
         for l in range(self.n_layers):
             k = 1.0 / math.sqrt(self.dims[l])
             self.weight(l).copy_(torch.empty(self.dims[l + 1], self.dims[l]).uniform_(-k, k, generator=g))
             self.bias(l).copy_(torch.empty(self.dims[l + 1]).uniform_(-k, k, generator=g))
+            if self.layernorm and l < self.n_layers - 1:
+                self.ln_weight(l).fill_(1.0)
+                self.ln_bias(l).zero_()
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
-        """nn.Sequential numbering of the reference: '0.weight', '0.bias', '2.weight', ..."""
+        """nn.Sequential numbering of the reference: '0.weight', '0.bias', '2.weight', ... (with LayerNorms: 0, 2 (LN), 3, 5 (LN), 6)"""
+        per = 3 if self.layernorm else 2
         for l in range(self.n_layers):
-            self.weight(l).copy_(torch.as_tensor(sd[f"{2 * l}.weight"], dtype=torch.float32))
-            self.bias(l).copy_(torch.as_tensor(sd[f"{2 * l}.bias"], dtype=torch.float32))
+            self.weight(l).copy_(torch.as_tensor(sd[f"{per * l}.weight"], dtype=torch.float32))
+            self.bias(l).copy_(torch.as_tensor(sd[f"{per * l}.bias"], dtype=torch.float32))
+            if self.layernorm and l < self.n_layers - 1:
+                self.ln_weight(l).copy_(torch.as_tensor(sd[f"{per * l + 2}.weight"], dtype=torch.float32))
+                self.ln_bias(l).copy_(torch.as_tensor(sd[f"{per * l + 2}.bias"], dtype=torch.float32))
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        per = 3 if self.layernorm else 2
+        out = {}
+        for l in range(self.n_layers):
+            out[f"{per * l}.weight"], out[f"{per * l}.bias"] = self.weight(l).cpu().clone(), self.bias(l).cpu().clone()
+            if self.layernorm and l < self.n_layers - 1:
+                out[f"{per * l + 2}.weight"], out[f"{per * l + 2}.bias"] = self.ln_weight(l).cpu().clone(), self.ln_bias(l).cpu().clone()
+        return out
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
