@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--workload", choices=["physics", "train", "auto"], default="auto")
     ap.add_argument("--family", type=int, default=0, help="SAC network family: 0 = reference shapes, 1 = 256x256 MLP")
     ap.add_argument("--dr-stage", type=int, default=None, help="train: domain randomisation at curriculum stage 0-5 (default: off)")
+    ap.add_argument("--shipped-acting", action="store_true", help="train: act like the reference under its shipped config.yaml "
+                                                                  "(hierarchical goal policy + safety layer + curiosity bonus)")
     ap.add_argument("--no-overlap", action="store_true", help="train: run the update after the acting pass instead of beside it")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per K steps")
     ap.add_argument("--graph", action="store_true", help="train: capture the K steps in one hipGraph (default: eager; the host "

@@ -50,3 +50,20 @@ def test_train_loop_in_one_hipgraph():
     aux = tr.env.export_state()["aux"].cpu().numpy()
     assert aux[:, 0].max() <= 15 + 1 and aux[:, 7].sum() > 0  # episodes ended and restarted inside the graph
     tr.close()
+
+
+def test_train_loop_with_the_shipped_acting_path():
+    """config.yaml defaults: the hierarchical policy acts, the safety layer corrects, SAC is what gets trained"""
+    from tvc_ai_amd.trainer import VecTrainer
+    tr = VecTrainer(384, family=0, batch_size=64, replay_capacity=4096, seed=9, enable_curiosity=True, enable_hierarchical=True,
+                    enable_safety=True)
+    p0 = tr.sac.params.clone()
+    low0 = tr.hier.low.params.clone()
+    for _ in range(8):
+        tr.step(True)
+    torch.cuda.synchronize()
+    assert np.all(np.isfinite(tr.stats()["losses"]))
+    assert tr.act.abs().max().item() <= 1.0 and torch.isfinite(tr.act).all()
+    assert not torch.equal(p0, tr.sac.params)              # the SAC nets learn ...
+    assert torch.equal(low0, tr.hier.low.params)           # ... the acting nets are never trained (as in the reference)
+    tr.close()

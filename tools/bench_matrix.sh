@@ -19,6 +19,7 @@ run --workload train --envs-per-gpu 8192 --steps 300 --warmup 30
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --dr-stage 5
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --no-overlap
+run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --shipped-acting
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --graph
 run --workload train --envs-per-gpu 4096 --steps 300 --warmup 30 --family 1
 run --workload train --envs-per-gpu 8192 --steps 300 --warmup 30 --family 1

@@ -18,7 +18,8 @@ from .parallel import GradSync, broadcast_parameters
 class VecTrainer:
     def __init__(self, num_envs: int, device="cuda:0", config: Optional[dict] = None, family: int = 0, batch_size: int = 256,
                  replay_capacity: int = 1_000_000, seed: int = 42, rank: int = 0, world: int = 1, updates_per_step: int = 1,
-                 max_episode_steps: int = 1000, enable_curiosity: bool = False, overlap: bool = True, **env_over):
+                 max_episode_steps: int = 1000, enable_curiosity: bool = False, overlap: bool = True,
+                 enable_hierarchical: bool = False, enable_safety: bool = False, **env_over):
         self.device = torch.device(device)
         self.n, self.B, self.world, self.rank = num_envs, batch_size, world, rank
         self.updates_per_step = updates_per_step
@@ -37,6 +38,17 @@ class VecTrainer:
         if enable_curiosity:
             from .curiosity import VecCuriosity
             self.curiosity = VecCuriosity(device=self.device, max_rows=num_envs, seed=seed)
+        # acting path of the shipped config.yaml (agent/...:751-754, 785-789): the never-trained hierarchical policy picks
+        # the action, the safety layer corrects it; the SAC policy is still what the updates train
+        self.hier = self.safety = None
+        if enable_hierarchical:
+            from .hierarchical import HierarchicalPolicy
+            self.hier = HierarchicalPolicy(10, 2, device=self.device, max_rows=num_envs, seed=seed + 11)
+            self.u_goal = torch.empty((num_envs,), device=self.device)
+        if enable_safety:
+            from .curiosity import SafetyLayer
+            self.safety = SafetyLayer(device=self.device, max_rows=num_envs, seed=seed + 12)
+            self.act_raw = torch.empty((num_envs, 2), device=self.device)
         d, n, B = self.device, num_envs, batch_size
         self.obs = [torch.empty((n, 10), device=d), torch.empty((n, 10), device=d)]
         self.cur = 0
@@ -60,12 +72,24 @@ class VecTrainer:
         self.rb.close()
         if self.curiosity is not None:
             self.curiosity.close()
+        if self.hier is not None:
+            self.hier.close()
+        if self.safety is not None:
+            self.safety.close()
 
     def collect(self):
         """act + env step + replay insert"""
         cur, nxt = self.obs[self.cur], self.obs[1 - self.cur]
         self.eps_act.normal_()
-        self.sac.act(cur, self.eps_act, out=(self.act, self.mean, self.ls))
+        raw = self.act_raw if self.safety is not None else self.act
+        if self.hier is not None:
+            self.u_goal.uniform_()
+            a, _, _, _ = self.hier.act(cur, self.eps_act, self.u_goal, clamp=self.safety is None)
+            raw.copy_(a)
+        else:
+            self.sac.act(cur, self.eps_act, out=(raw, self.mean, self.ls), clamp=self.safety is None)
+        if self.safety is not None:  # sees the unclamped sample; clamps its result
+            self.safety.apply(cur, raw, out=self.act)
         o, rew, term, trunc, info = self.env.step(self.act, out_obs=nxt)
         if self.curiosity is not None:  # added after the env's clip, skipped on the first step of an episode
             self.curiosity.add_intrinsic_reward(cur, self.act, info["final_observation"], rew, self.prev_done)
@@ -132,13 +156,17 @@ def bench_train(args, world, rank, device):
     if stage is not None:  # BASELINE configs[4]: full domain randomisation at a curriculum stage (config.yaml:236-286, 340-349)
         from .env import dr_from_yaml
         env_over = dr_from_yaml({}, stage)
+    shipped = bool(getattr(args, "shipped_acting", False))
     tr = VecTrainer(args.envs_per_gpu, device=device, family=family, batch_size=256, replay_capacity=1_000_000, seed=42,
-                    rank=rank, world=world, updates_per_step=1, overlap=not getattr(args, "no_overlap", False), **env_over)
+                    rank=rank, world=world, updates_per_step=1, overlap=not getattr(args, "no_overlap", False),
+                    enable_hierarchical=shipped, enable_safety=shipped, enable_curiosity=shipped, **env_over)
     fam = "reference shapes (seq-len-1 transformer actor 2.26M trainable params, 512/256 GELU+LN critics)" if family == 0 \
         else "256x256 ReLU MLP actor/critics"
     return {"step_fn": lambda k: tr.step(True), "env": tr.env, "trainer": tr,
             "extra": {"updates_per_step": 1.0, "sac": {"family": fam, "batch": 256, "replay_capacity": 1_000_000,
                                                       "utd": "1 update per vector step", "dtype": "f32 MFMA",
+                                                      "acting": "hierarchical goal policy + safety layer + curiosity bonus (shipped config.yaml)"
+                                                      if shipped else "SAC policy",
                                                       "domain_randomisation": "off (shipped env)" if stage is None
                                                       else f"curriculum stage {stage}: {env_over}"}}}
 
