@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--workload", choices=["physics", "train", "auto"], default="auto")
     ap.add_argument("--family", type=int, default=0, help="SAC network family: 0 = reference shapes, 1 = 256x256 MLP")
     ap.add_argument("--dr-stage", type=int, default=None, help="train: domain randomisation at curriculum stage 0-5 (default: off)")
+    ap.add_argument("--updates-per-step", type=int, default=1, help="train: SAC updates per vector step (they run beside the "
+                                                                      "acting pass on the second stream)")
     ap.add_argument("--shipped-acting", action="store_true", help="train: act like the reference under its shipped config.yaml "
                                                                   "(hierarchical goal policy + safety layer + curiosity bonus)")
     ap.add_argument("--no-overlap", action="store_true", help="train: run the update after the acting pass instead of beside it")

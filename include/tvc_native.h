@@ -197,6 +197,11 @@ void tvc_sac_destroy(tvc_sac* sac);
  * (initialisation, checkpoint load, parameter broadcast). */
 int tvc_sac_sync_derived(tvc_sac* sac, void* stream);
 
+/* Copies the policy parameters (and the folded acting weights) into a library-owned snapshot; tvc_sac_act with flags
+ * bit 1 reads that snapshot.  Lets the learner keep stepping the live parameters on another stream while the acting
+ * pass of the same vector step runs (the policy that acts during step t is the one left by step t-1 either way). */
+int tvc_sac_snapshot_policy(tvc_sac* sac, void* stream);
+
 /* Adam step counters {critics, actor} (device-resident so that a captured update keeps counting); checkpoints only,
  * both calls synchronise. */
 int tvc_sac_get_adam_steps(tvc_sac* sac, int32_t out[2]);
@@ -204,7 +209,7 @@ int tvc_sac_set_adam_steps(tvc_sac* sac, const int32_t in[2]);
 
 /* Policy part of get_action (agent/...:765-789) for n rows: mean/log_std (clamped to [-20,2]) and
  * action = clamp(mean + exp(log_std) * eps, -1, 1); eps_dev NULL = deterministic (action = clamp(mean)).
- * flags bit 0: do not clamp (the safety layer sees the raw sample, agent/...:780-789).
+ * flags bit 0: do not clamp (the safety layer sees the raw sample, agent/...:780-789); bit 1: act with the snapshot.
  * obs_dev float[n,obs]; act_dev float[n,A]; mean_dev / logstd_dev float[n,A] or NULL. */
 int tvc_sac_act(tvc_sac* sac, const float* obs_dev, int32_t n, const float* eps_dev, float* act_dev, float* mean_dev,
                 float* logstd_dev, int32_t flags, void* stream);

@@ -594,6 +594,8 @@ struct tvc_sac {
     NetDef actor, critic, actor_inf;
     FoldInfo fold;
     float* ov = nullptr;  // [layers][d*d + d] folded attention weights of the acting net
+    float *snap_p = nullptr, *snap_ov = nullptr;  // acting snapshot of the policy parameters / folded weights
+    long ov_floats = 0;
     long n_actor, n_critic;
     float *params, *grads, *adam_m, *adam_v;  // caller-owned
     void* slab = nullptr;                      // library-owned workspace
@@ -741,7 +743,8 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     long bytes = ctx_bytes(h->actor, 2 * B, 1, true) + ctx_bytes(h->critic, B, 2, true) + 8L * NA * maxd * 4 + 2L * B * cfg->obs_dim * 4 + 512;
     bytes += (long)cfg->pe_rows * cfg->d_model * 4 + (long)B * (cfg->obs_dim + A) * 4 * 2 + (long)B * 64 + (1 << 16);
     bytes += 256L * (4 * (h->actor.buf_dim.size() + h->critic.buf_dim.size()) * 3 + 64);
-    bytes += (long)std::max(1, h->fold.layers) * ((long)h->fold.d * h->fold.d + h->fold.d + 4) * 4 + 1024;
+    h->ov_floats = (long)std::max(1, h->fold.layers) * ((long)h->fold.d * h->fold.d + h->fold.d + 4);
+    bytes += 2 * h->ov_floats * 4 + h->n_actor * 4 + 2048;
     hipError_t he = hipMalloc(&h->slab, bytes);
     if (he != hipSuccess) {
         delete h;
@@ -765,7 +768,9 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     h->y = (float*)carve(p, (long)B * 4);
     h->dq = (float*)carve(p, (long)B * 2 * 4);
     h->clk = (AdamClock*)carve(p, 2 * sizeof(AdamClock));
-    h->ov = (float*)carve(p, (long)std::max(1, h->fold.layers) * ((long)h->fold.d * h->fold.d + h->fold.d + 4) * 4);
+    h->ov = (float*)carve(p, h->ov_floats * 4);
+    h->snap_ov = (float*)carve(p, h->ov_floats * 4);
+    h->snap_p = (float*)carve(p, h->n_actor * 4);
     if ((long)(p - (char*)h->slab) > bytes) {
         (void)hipFree(h->slab);
         delete h;
@@ -813,8 +818,9 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
     const int A = h->cfg.act_dim;
     // activation group strides depend on the row count actually used
     for (size_t b = 1; b < h->ictx.gY.size(); ++b) h->ictx.gY[b] = (long)n * h->actor_inf.buf_dim[b];
-    net_forward(h->actor_inf, h->P_actor(), 0, obs, 0, n, 1, h->ictx, false, h->cfg.family == 0 ? h->pe : nullptr, h->cfg.pe_rows, st,
-                h->ov);
+    const bool snap = (flags & 2) != 0;  // read the snapshot taken by tvc_sac_snapshot_policy instead of the live parameters
+    net_forward(h->actor_inf, snap ? h->snap_p : h->P_actor(), 0, obs, 0, n, 1, h->ictx, false, h->cfg.family == 0 ? h->pe : nullptr,
+                h->cfg.pe_rows, st, snap ? h->snap_ov : h->ov);
     const float* head = h->ictx.Y.back();
     hipLaunchKernelGGL(sample_action_kernel, dim3((n * A + 255) / 256), dim3(256), 0, st, head, eps, act, mean, logstd, n, A,
                        (flags & 1) ? 0 : 1);
@@ -970,6 +976,15 @@ int tvc_sac_set_adam_steps(tvc_sac* h, const int32_t in[2]) {
     if (in[0] < 0 || in[1] < 0) return tvc::set_error(TVC_EINVAL, "negative step count");
     TVC_HIP_CHECK(hipSetDevice(h->device));
     return set_clocks(h, in);
+}
+
+int tvc_sac_snapshot_policy(tvc_sac* h, void* stream) {
+    if (!h) return tvc::set_error(TVC_EINVAL, "null argument");
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    TVC_HIP_CHECK(hipMemcpyAsync(h->snap_p, h->P_actor(), h->n_actor * sizeof(float), hipMemcpyDeviceToDevice, st));
+    TVC_HIP_CHECK(hipMemcpyAsync(h->snap_ov, h->ov, h->ov_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
 }
 
 int tvc_sac_sync_derived(tvc_sac* h, void* stream) {

@@ -56,10 +56,13 @@ class VecTrainer:
         self.mean = torch.empty((n, 2), device=d)
         self.ls = torch.empty((n, 2), device=d)
         self.eps_act = torch.empty((n, 2), device=d)
-        self.eps1 = torch.empty((B, 2), device=d)
-        self.eps2 = torch.empty((B, 2), device=d)
-        self.batch = (torch.empty((B, 10), device=d), torch.empty((B, 2), device=d), torch.empty((B,), device=d),
-                      torch.empty((B, 10), device=d), torch.empty((B,), device=d))
+        K = max(1, updates_per_step)
+        self.eps1 = [torch.empty((B, 2), device=d) for _ in range(K)]
+        self.eps2 = [torch.empty((B, 2), device=d) for _ in range(K)]
+        self.batches = [(torch.empty((B, 10), device=d), torch.empty((B, 2), device=d), torch.empty((B,), device=d),
+                         torch.empty((B, 10), device=d), torch.empty((B,), device=d)) for _ in range(K)]
+        self.batch = self.batches[0]
+        self._snapshot = False  # collect() acts with the policy snapshot (overlapped schedule)
         self.prev_done = torch.ones((n,), dtype=torch.uint8, device=d)  # 1 = next step is the first of an episode
         torch.manual_seed(seed + rank)  # default CUDA generator: hipGraph-capturable normal draws
         o, _ = self.env.reset()
@@ -87,7 +90,7 @@ class VecTrainer:
             a, _, _, _ = self.hier.act(cur, self.eps_act, self.u_goal, clamp=self.safety is None)
             raw.copy_(a)
         else:
-            self.sac.act(cur, self.eps_act, out=(raw, self.mean, self.ls), clamp=self.safety is None)
+            self.sac.act(cur, self.eps_act, out=(raw, self.mean, self.ls), clamp=self.safety is None, snapshot=self._snapshot)
         if self.safety is not None:  # sees the unclamped sample; clamps its result
             self.safety.apply(cur, raw, out=self.act)
         o, rew, term, trunc, info = self.env.step(self.act, out_obs=nxt)
@@ -97,51 +100,53 @@ class VecTrainer:
         self.rb.insert(cur, self.act, rew, info["final_observation"], term, trunc)
         self.cur = 1 - self.cur
 
-    def learn(self):
-        self.rb.sample(self.B, out=self.batch)
-        self.eps1.normal_()
-        self.eps2.normal_()
-        s, a, r, s2, d = self.batch
+    def learn(self, k: int = 0):
+        self.rb.sample(self.B, out=self.batches[k])
+        self.eps1[k].normal_()
+        self.eps2[k].normal_()
+        s, a, r, s2, d = self.batches[k]
         gs = self.sync.grad_scale if self.sync is not None else 1.0
-        return self.sac.update(s, a, r, s2, d, self.eps1, self.eps2, all_reduce=self.sync, grad_scale=gs)
+        return self.sac.update(s, a, r, s2, d, self.eps1[k], self.eps2[k], all_reduce=self.sync, grad_scale=gs)
 
     def step(self, learn: bool = True):
-        if learn and self.overlap and self.steps > 0 and self.updates_per_step == 1:
+        if learn and self.overlap and self.steps > 0:
             self._step_overlapped()
         else:
             self.collect()
             if learn:
-                for _ in range(self.updates_per_step):
-                    self.learn()
+                for k in range(self.updates_per_step):
+                    self.learn(k)
         self.steps += 1
 
     def _step_overlapped(self):
-        """Same work as collect() + learn(), on two HIP streams: the update's gradient phases (hundreds of
-        latency-bound batch-256 kernels, plus the RCCL all-reduces when data parallel) run beside the acting pass
-        (large GEMMs over all envs).  Only the actor's Adam step waits for both, because acting reads the policy
-        parameters.  The batch is drawn before this step's transitions are inserted."""
+        """Same work as collect() + updates_per_step x learn(), on two HIP streams.  The acting pass (large GEMMs over
+        all envs) reads a SNAPSHOT of the policy taken at the start of the step, so the whole update -- gradient phases
+        (hundreds of latency-bound batch-256 kernels), the RCCL all-reduces when data parallel, and both Adam steps --
+        runs beside it on the side stream; the two streams meet once per step.  The policy that acts during step t is
+        the one left by step t-1, exactly as in the sequential schedule.  All batches of the step are drawn before its
+        transitions are inserted (no read of a row that is being overwritten)."""
         main = torch.cuda.current_stream(self.device)
         sac, side = self.sac, self._side
-        self.rb.sample(self.B, out=self.batch)
-        self.eps1.normal_()
-        self.eps2.normal_()
-        s, a, r, s2, d = self.batch
+        for k in range(self.updates_per_step):
+            self.rb.sample(self.B, out=self.batches[k])
+            self.eps1[k].normal_()
+            self.eps2[k].normal_()
+        sac.snapshot_policy()
         gs = self.sync.grad_scale if self.sync is not None else 1.0
         self._fork.record(main)
-        # the acting pass is enqueued FIRST: the host needs hundreds of microseconds to enqueue the ~100 learner launches,
-        # and the GPU would otherwise sit idle on the main stream for that long at small env counts
-        self.collect()
+        # the acting pass is enqueued FIRST: the host needs hundreds of microseconds to enqueue the ~100 learner launches
+        # of an update, and the GPU would otherwise sit idle on the main stream for that long at small env counts
+        self._snapshot = True
+        try:
+            self.collect()
+        finally:
+            self._snapshot = False
         side.wait_event(self._fork)
         with torch.cuda.stream(side):
-            sac.critic_grads(s, a, r, s2, d, self.eps1)
-            if self.sync is not None:
-                self.sync(sac.grads[sac.n_policy:])
-            sac.critic_apply(gs)
-            sac.actor_grads(s, self.eps2)
-            if self.sync is not None:
-                self.sync(sac.grads[:sac.n_policy])
+            for k in range(self.updates_per_step):
+                s, a, r, s2, d = self.batches[k]
+                sac.update(s, a, r, s2, d, self.eps1[k], self.eps2[k], all_reduce=self.sync, grad_scale=gs)
         main.wait_stream(side)
-        sac.actor_apply(gs)
 
     def stats(self):
         return {"env_steps": self.steps * self.n, "updates": self.steps * self.updates_per_step,
@@ -157,14 +162,15 @@ def bench_train(args, world, rank, device):
         from .env import dr_from_yaml
         env_over = dr_from_yaml({}, stage)
     shipped = bool(getattr(args, "shipped_acting", False))
+    utd = max(1, int(getattr(args, "updates_per_step", 1)))
     tr = VecTrainer(args.envs_per_gpu, device=device, family=family, batch_size=256, replay_capacity=1_000_000, seed=42,
-                    rank=rank, world=world, updates_per_step=1, overlap=not getattr(args, "no_overlap", False),
+                    rank=rank, world=world, updates_per_step=utd, overlap=not getattr(args, "no_overlap", False),
                     enable_hierarchical=shipped, enable_safety=shipped, enable_curiosity=shipped, **env_over)
     fam = "reference shapes (seq-len-1 transformer actor 2.26M trainable params, 512/256 GELU+LN critics)" if family == 0 \
         else "256x256 ReLU MLP actor/critics"
     return {"step_fn": lambda k: tr.step(True), "env": tr.env, "trainer": tr,
-            "extra": {"updates_per_step": 1.0, "sac": {"family": fam, "batch": 256, "replay_capacity": 1_000_000,
-                                                      "utd": "1 update per vector step", "dtype": "f32 MFMA",
+            "extra": {"updates_per_step": float(utd), "sac": {"family": fam, "batch": 256, "replay_capacity": 1_000_000,
+                                                      "utd": f"{utd} update(s) per vector step", "dtype": "f32 MFMA",
                                                       "acting": "hierarchical goal policy + safety layer + curiosity bonus (shipped config.yaml)"
                                                       if shipped else "SAC policy",
                                                       "domain_randomisation": "off (shipped env)" if stage is None
