@@ -273,3 +273,63 @@ def test_checkpoint_layout_and_round_trip(tmp_path):
     np.testing.assert_allclose(act_a, act_b, atol=1e-6)
     assert torch.equal(a.sac.params, b.sac.params) and torch.equal(a.sac.adam_v, b.sac.adam_v)
     assert b.sac.adam_steps() == [3, 3]
+
+
+def test_gradients_match_autograd_of_the_restatement():
+    """the backward kernels on their own: grads after tvc_sac_critic_grads / tvc_sac_actor_grads vs torch.autograd of the
+    oracle's losses (same parameters, batch and noise), before any optimiser step can blur the comparison"""
+    from tvc_ai_amd.agent import NativeSAC, sac_cfg, _ref_to_native_name
+    torch.set_num_threads(8)
+    rec = _recipe()
+    meta = json.load(open(os.path.join(HERE, "golden", "sac_ref_meta.json")))
+    rng = np.random.default_rng(meta["seed"])
+    nets = ref_nets(rec, meta, rng)
+    B = 256
+    sac = NativeSAC(sac_cfg(0, batch_size=B, max_act_rows=B), init=False)
+    load_into_native(sac, nets)
+    s, a, r, s2, d = [torch.from_numpy(x) for x in rec.make_batch(rng)]
+    e1 = torch.from_numpy(rng.standard_normal((B, 2)).astype(np.float32))
+    e2 = torch.from_numpy(rng.standard_normal((B, 2)).astype(np.float32))
+    sg, ag, rg, s2g, dg, e1g, e2g = cuda(s, a, r, s2, d, e1, e2)
+    orc = st.SacOracle(nets["policy"], nets["q1"], nets["q2"], batch_pe=False)
+
+    def close(got, want, what):
+        scale = want.abs().max().item()
+        err = (got.cpu() - want).abs().max().item()
+        assert err <= 2e-4 * scale + 1e-7, (what, err, scale)
+
+    # critic phase
+    sac.critic_grads(sg, ag, rg, s2g, dg, e1g)
+    with torch.no_grad():
+        m2, ls2 = orc.actor_fn(orc.P, s2)
+        a2 = m2 + torch.exp(ls2) * e1
+        y = r + st.GAMMA * (1 - d) * torch.min(orc.critic_fn(orc.TQ[0], s2, a2), orc.critic_fn(orc.TQ[1], s2, a2))
+    for i, net in enumerate(("q1", "q2")):
+        loss = torch.nn.functional.mse_loss(orc.critic_fn(orc.Q[i], s, a), y)
+        keys = list(orc.Q[i].keys())
+        grads = torch.autograd.grad(loss, [orc.Q[i][k] for k in keys])
+        for k, gr in zip(keys, grads):
+            close(sac.grad_view(f"{net}.{k}").reshape(gr.shape), gr, f"{net}.{k}")
+        orc.opt_q[i].step(orc.Q[i], dict(zip(keys, grads)))
+    sac.critic_apply()
+    # actor phase (through the UPDATED critics, data gradients only)
+    sac.actor_grads(sg, e2g)
+    mean, ls = orc.actor_fn(orc.P, s)
+    std = torch.exp(ls)
+    a_new = mean + std * e2
+    logp = (-((a_new - mean) ** 2) / (2 * std ** 2) - ls - np.log(np.sqrt(2 * np.pi))).sum(-1)
+    ploss = -(torch.min(orc.critic_fn(orc.Q[0], s, a_new), orc.critic_fn(orc.Q[1], s, a_new)) - st.ALPHA * logp).mean()
+    names = list(orc.P.keys())
+    grads = torch.autograd.grad(ploss, [orc.P[k] for k in names], allow_unused=True)
+    dm, checked = sac.cfg.d_model, 0
+    for k, gr in zip(names, grads):
+        if k.startswith("value_head") or k.startswith("pos_encoding") or gr is None:
+            continue
+        name, sl = _ref_to_native_name("policy", k)
+        if sl == "v_rows":
+            assert gr[:2 * dm].abs().max().item() == 0.0  # Q/K projection rows are dead at sequence length 1
+            gr = gr[2 * dm:3 * dm]
+        close(sac.grad_view(name).reshape(gr.shape), gr, name)
+        checked += 1
+    assert checked >= 60
+    sac.close()
