@@ -363,23 +363,36 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
         # the timed region holds exactly K launches of this one kernel: launch duration = HIP-event time / K
         rep["roofline"] = integrator_roofline(n, device, us=dev_us_per_step)
     else:
-        # dominant kernel of the train loop = the fused Linear GEMM of the acting pass (M = envs, 256x256 layers:
-        # 8 of its 13 GEMMs), fp32-input MFMA (v_mfma_f32_16x16x4_f32), dense peak 157.3 TFLOP/s
+        # dominant kernel of the train loop = the fused Linear + residual + LayerNorm of the acting pass (M = envs;
+        # the K = 512 -> N = 256 FFN-out layer is the largest single line of the kernel trace, profiles/), fp32-input
+        # MFMA (v_mfma_f32_16x16x4_f32), dense peak 157.3 TFLOP/s.  Small N (< 6144 rows) runs the unfused 64x64 kernel.
         from tvc_ai_amd import _native as nat
         L = nat.load()
-        M, N, K = n, 256, 256
+        M, N, K = n, 256, 512
         X = torch.randn(M, K, device=device)
         W = torch.randn(N, K, device=device) / 16
         b = torch.zeros(N, device=device)
+        R = torch.randn(M, N, device=device)
+        gam, bet = torch.ones(N, device=device), torch.zeros(N, device=device)
         Y = torch.empty(M, N, device=device)
-        st = torch.cuda.current_stream(device)
-        us = graph_time_us(lambda k: L.tvc_nn_linear_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, N, K, 0, 0,
-                                                             torch.cuda.current_stream(device).cuda_stream), 20, device)
+        fused = M >= 6144
+        if fused:
+            kname = "tvcnn::gemm_rowln_kernel<4, 32> (Linear 512->256 + residual + LayerNorm, M = envs)"
+            us = graph_time_us(lambda k: L.tvc_nn_linear_ln_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(),
+                                                                    gam.data_ptr(), bet.data_ptr(), Y.data_ptr(), M, N, K, 0,
+                                                                    torch.cuda.current_stream(device).cuda_stream), 20, device)
+            traffic = pmc_traffic(((M + 31) // 32) * 256, "tvcnn::gemm_rowln_kernel<4, 32>")
+        else:
+            kname = "tvcnn::gemm_kernel<true,true> (Linear 512->256, M = envs)"
+            us = graph_time_us(lambda k: L.tvc_nn_linear_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, N, K, 0,
+                                                                 0, torch.cuda.current_stream(device).cuda_stream), 20, device)
+            traffic = pmc_traffic((N // 64) * ((M + 63) // 64) * 256, "tvcnn::gemm_kernel")
         tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
-        rep["roofline"] = {"bound": "mfma", "kernel": "tvcnn::gemm_kernel<true,true> (Linear 256->256, M = envs)", "achieved": tf,
+        rep["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": tf,
                            "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
-                           "traffic": pmc_traffic((N // 64) * ((M + 63) // 64) * 256, "tvcnn::gemm_kernel"),
-                           "launch_us": us, "flops_per_launch": 2.0 * M * N * K, "dtype": "f32 in / f32 acc MFMA"}
+                           "traffic": traffic, "launch_us": us, "flops_per_launch": 2.0 * M * N * K,
+                           "dtype": "f32 in / f32 acc MFMA"}
+        del R, gam, bet
         del X, W, b, Y
         rep["roofline_integrator"] = integrator_roofline(n, device)
         # learner alone (no env stepping): back-to-back SAC updates at B = 256 on a fixed batch

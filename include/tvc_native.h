@@ -240,6 +240,12 @@ int tvc_sac_update(tvc_sac* sac, const float* s, const float* a, const float* r,
 int tvc_nn_linear_forward(const float* X, const float* W, const float* b, float* Y, int32_t M, int32_t N, int32_t K,
                           int32_t act, int32_t variant, void* stream);
 
+/* The fused acting-pass kernel on its own: Y[M,N] = LayerNorm(act(X W^T + b) + R) * gamma + beta (eps 1e-5), i.e. one
+ * nn.Linear + activation + residual + nn.LayerNorm of the policy (agent/multi_algorithm_agent.py:137-170) in one launch,
+ * 32 complete rows per workgroup.  N in {256, 512}, K a multiple of 16; b, R may be NULL. */
+int tvc_nn_linear_ln_forward(const float* X, const float* W, const float* b, const float* R, const float* gamma,
+                             const float* beta, float* Y, int32_t M, int32_t N, int32_t K, int32_t act, void* stream);
+
 /* critic forward q1(s,a), q2(s,a) for n <= batch_size rows (tests / diagnostics): q_dev float[2,n] */
 int tvc_sac_q_values(tvc_sac* sac, const float* s, const float* a, int32_t n, int32_t use_target, float* q_dev, void* stream);
 

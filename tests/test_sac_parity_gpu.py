@@ -333,3 +333,22 @@ def test_gradients_match_autograd_of_the_restatement():
         checked += 1
     assert checked >= 60
     sac.close()
+
+
+@pytest.mark.parametrize("M,N,K,act", [(8192, 256, 512, 0), (6145, 256, 256, 0), (7000, 512, 256, 1), (6400, 512, 512, 1)])
+def test_fused_linear_layernorm_kernel_vs_torch_fp32(M, N, K, act):
+    """the acting-pass kernel (Linear + act + residual + LayerNorm in one launch, 32 complete rows per workgroup) on its own"""
+    from tvc_ai_amd import _native as nat
+    L = nat.load()
+    g = torch.Generator().manual_seed(M + N + K)
+    X, W = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5
+    b, R = 0.1 * torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    gam, bet = 1 + 0.1 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    z = torch.nn.functional.linear(X, W, b)
+    z = torch.nn.functional.gelu(z) if act == 1 else z
+    want = torch.nn.functional.layer_norm(z + R, (N,), gam, bet, 1e-5)
+    Xg, Wg, bg, Rg, gg, beg = cuda(X, W, b, R, gam, bet)
+    Y = torch.empty(M, N, device="cuda")
+    nat.check(L.tvc_nn_linear_ln_forward(Xg.data_ptr(), Wg.data_ptr(), bg.data_ptr(), Rg.data_ptr(), gg.data_ptr(), beg.data_ptr(),
+                                         Y.data_ptr(), M, N, K, act, torch.cuda.current_stream().cuda_stream))
+    np.testing.assert_allclose(Y.cpu().numpy(), want.numpy(), atol=3e-5, rtol=1e-5)

@@ -1,11 +1,23 @@
 """Workload for rocprofv3 --pmc passes.
   pmc_run.py env 8192 65536 4194304   -> eager env_step launches at those sizes
-  pmc_run.py gemm 65536 256 256       -> the acting-pass Linear kernel at M N K (tvc_nn_linear_forward)"""
+  pmc_run.py gemm 65536 256 256       -> the acting-pass Linear kernel at M N K (tvc_nn_linear_forward)
+  pmc_run.py rowln 65536 256 512      -> the fused Linear + residual + LayerNorm kernel (tvc_nn_linear_ln_forward)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 mode = sys.argv[1] if len(sys.argv) > 1 else "env"
-if mode == "gemm":
+if mode == "rowln":  # pmc_run.py rowln M N K -> the fused Linear + residual + LayerNorm acting kernel
+    from tvc_ai_amd import _native as nat
+    L = nat.load()
+    M, N, K = [int(x) for x in sys.argv[2:5]]
+    X = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.zeros(N, device="cuda")
+    R = torch.randn(M, N, device="cuda"); g = torch.ones(N, device="cuda"); be = torch.zeros(N, device="cuda")
+    Y = torch.empty(M, N, device="cuda")
+    for _ in range(20):
+        nat.check(L.tvc_nn_linear_ln_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), g.data_ptr(), be.data_ptr(),
+                                             Y.data_ptr(), M, N, K, 0, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+elif mode == "gemm":
     from tvc_ai_amd import _native as nat
     L = nat.load()
     M, N, K = [int(x) for x in sys.argv[2:5]]

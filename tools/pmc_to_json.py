@@ -13,7 +13,9 @@ def collect(d, counter):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != counter:
                 continue
-            name = re.sub(r"\(anonymous namespace\)::|^void ", "", row["Kernel_Name"]).split("(")[0].split("<")[0]
+            name = re.sub(r"\(anonymous namespace\)::|^void ", "", row["Kernel_Name"]).split("(")[0]
+            if "gemm_rowln" not in name:  # the fused kernel keeps its template arguments: <JT, k-tiles> tell the shapes apart
+                name = name.split("<")[0]
             acc[(name, int(row["Grid_Size"]))].append(float(row["Counter_Value"]))
     return {k: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in acc.items()}
 
@@ -22,12 +24,17 @@ fetch = collect(sys.argv[1], "FETCH_SIZE")
 write = collect(sys.argv[2], "WRITE_SIZE")
 out = defaultdict(dict)
 for (name, grid), f in fetch.items():
-    if (name, grid) not in write or not ("env_step" in name or "gemm_kernel" in name):
+    if (name, grid) not in write or not ("env_step" in name or "gemm_kernel" in name or "gemm_rowln" in name):
         continue
     w = write[(name, grid)]
     out[name][str(grid)] = {"fetch_size_kib_raw": f, "write_size_kib": w, "hbm_read_bytes": f * 1024 * 2,
                             "hbm_write_bytes": w * 1024, "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024,
                             "hbm_bytes_per_thread": (f * 1024 * 2 + w * 1024) / grid}
 path = sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic.json"
+if os.path.exists(path):  # merge into what earlier passes measured
+    old = json.load(open(path))
+    for k, v in old.items():
+        for g, e in v.items():
+            out[k].setdefault(g, e)
 json.dump(out, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -99,6 +99,7 @@ SIGNATURES.update({
     "tvc_sac_actor_apply": (C.c_int, [_VP, C.c_float, _VP]),
     "tvc_sac_update": (C.c_int, [_VP] + [_VP] * 9),
     "tvc_sac_q_values": (C.c_int, [_VP, _VP, _VP, C.c_int32, C.c_int32, _VP, _VP]),
+    "tvc_nn_linear_ln_forward": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP]),
     "tvc_nn_linear_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP]),
     "tvc_replay_create": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_VP)]),
     "tvc_replay_destroy": (None, [_VP]),

@@ -335,7 +335,7 @@ __device__ __forceinline__ void rowln_normalize(f32x4 (&u)[2][JT], float* red, c
     }
 }
 
-template <int JT>
+template <int JT, int KS>  // KS: k-tiles (K / 16) when known at compile time (the reference shapes: 16 or 32), 0 = runtime
 __global__ void __launch_bounds__(256) gemm_rowln_kernel(RowLnArgs g) {
     constexpr int N = 64 * JT;  // 4 waves x JT tiles x 16 columns
     __shared__ __attribute__((aligned(16))) float As[32][GLD];
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(256) gemm_rowln_kernel(RowLnArgs g) {
     f32x4 ra = *(cv4)ap, rb[JT];
 #pragma unroll
     for (int p = 0; p < JT; ++p) rb[p] = *(cv4)(bp + (long)(64 * p) * g.ldb);
-    const int nk = g.K / GBK;
+    const int nk = KS > 0 ? KS : g.K / GBK;
     const int l15 = lane & 15, fk = (lane >> 4) * 4;
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();

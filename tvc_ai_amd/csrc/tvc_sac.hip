@@ -217,6 +217,22 @@ static void launch_gemm(bool a_kc, bool b_kc, const GemmArgs& g, int G, hipStrea
     else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, st, g);
 }
 
+// fused Linear (+act, +residual) + LayerNorm(s), 32 complete rows per workgroup; the k-tile count is a template
+// parameter for the reference shapes (K = 256, 512), which also gives each shape its own kernel name in a profile
+static void launch_rowln(const RowLnArgs& a, hipStream_t st) {
+    const dim3 grid((a.M + 31) / 32), block(256);
+    const int ks = a.K / GBK;
+#define TVC_ROWLN(JT)                                                                               \
+    do {                                                                                            \
+        if (ks == 16) hipLaunchKernelGGL((gemm_rowln_kernel<JT, 16>), grid, block, 0, st, a);       \
+        else if (ks == 32) hipLaunchKernelGGL((gemm_rowln_kernel<JT, 32>), grid, block, 0, st, a);  \
+        else hipLaunchKernelGGL((gemm_rowln_kernel<JT, 0>), grid, block, 0, st, a);                 \
+    } while (0)
+    if (a.N == 256) TVC_ROWLN(4);
+    else TVC_ROWLN(8);
+#undef TVC_ROWLN
+}
+
 // dW = dZ^T X and dX = dZ W of one Linear in one launch when both fit the split-K kernel's fast path
 static void launch_gemm_bwd_pair(const GemmArgs& w, const GemmArgs& x, int G, hipStream_t st) {
     auto fast = [](const GemmArgs& g) {
@@ -282,8 +298,7 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
             a.Radd = o.res >= 0 ? (o.res == 0 ? X : c.Y[o.res]) : nullptr;
             a.gamma = P + ln.w; a.beta = P + ln.b;
             if (two) { a.gamma2 = P + nd.ops[i + 2].w; a.beta2 = P + nd.ops[i + 2].b; }
-            if (o.out_dim == 256) hipLaunchKernelGGL((gemm_rowln_kernel<4>), dim3((M + 31) / 32), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((gemm_rowln_kernel<8>), dim3((M + 31) / 32), dim3(256), 0, st, a);
+            launch_rowln(a, st);
             i += two ? 2 : 1;
             continue;
         }
@@ -1026,6 +1041,20 @@ int tvc_nn_linear_forward(const float* X, const float* W, const float* b, float*
     g_force_variant = variant;
     launch_gemm(true, true, g, 1, (hipStream_t)stream);
     g_force_variant = 0;
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Y = LayerNorm(act(X W^T + b) + R): the fused acting kernel on its own (numerics tests, roofline measurement)
+int tvc_nn_linear_ln_forward(const float* X, const float* W, const float* b, const float* R, const float* gamma, const float* beta,
+                             float* Y, int32_t M, int32_t N, int32_t K, int32_t act, void* stream) {
+    if (!X || !W || !Y || !gamma || !beta || M < 1) return tvc::set_error(TVC_EINVAL, "bad argument");
+    if ((N != 256 && N != 512) || K < GBK || (K % GBK) != 0) return tvc::set_error(TVC_EINVAL, "needs N in {256, 512}, K a multiple of 16");
+    if ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(W)) & 15) return tvc::set_error(TVC_EINVAL, "X, W must be 16-byte aligned");
+    RowLnArgs a{};
+    a.A = X; a.B = W; a.C = Y; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = K; a.ldc = N; a.bias = b; a.act = act; a.Radd = R;
+    a.gamma = gamma; a.beta = beta;
+    launch_rowln(a, (hipStream_t)stream);
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }
