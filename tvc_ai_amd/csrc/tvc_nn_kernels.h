@@ -289,6 +289,9 @@ struct RowLnArgs {
     const float* Radd;                    // residual added before the norm (ldc)
     const float* gamma; const float* beta;
     const float* gamma2; const float* beta2;  // optional second LayerNorm
+    // optional output head behind the norm (Linear(N -> headN <= 4), the policy's mean / log_std layer): when set, the
+    // normalised rows are NOT stored; only headOut[M, headN] = rows . headW^T + headB is
+    const float* headW; const float* headB; float* headOut; int headN;
 };
 
 template <int JT>  // 16-column MFMA tiles per wave; N = 4 waves * JT * 16  (JT = 4 -> 256, JT = 8 -> 512)
@@ -398,6 +401,39 @@ __global__ void __launch_bounds__(256) gemm_rowln_kernel(RowLnArgs g) {
     }
     rowln_normalize<JT>(acc, red, g.gamma, g.beta, wave, lane, N);
     if (g.gamma2) rowln_normalize<JT>(acc, red, g.gamma2, g.beta2, wave, lane, N);
+    if (g.headW) {  // dot every complete row with the head's weight rows: per-wave partials meet through LDS
+        __shared__ float hred[4][32][4];
+        for (int o = 0; o < g.headN; ++o) {
+            float part[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part[i][r] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const float w = g.headW[(long)o * N + wave * 16 * JT + j * 16 + l15];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part[i][r] = fmaf(acc[i][j][r], w, part[i][r]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = part[i][r];
+                    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                    if (l15 == 0) hred[wave][i * 16 + q * 4 + r][o] = v;
+                }
+        }
+        __syncthreads();
+        if (tid < 32 * g.headN) {
+            const int rl = tid / g.headN, o = tid - rl * g.headN;
+            const float v = hred[0][rl][o] + hred[1][rl][o] + hred[2][rl][o] + hred[3][rl][o] + g.headB[o];
+            if (m0 + rl < g.M) g.headOut[(long)(m0 + rl) * g.headN + o] = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < JT; ++j) {
         const int col = wave * 16 * JT + j * 16 + l15;

@@ -298,8 +298,19 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
             a.Radd = o.res >= 0 ? (o.res == 0 ? X : c.Y[o.res]) : nullptr;
             a.gamma = P + ln.w; a.beta = P + ln.b;
             if (two) { a.gamma2 = P + nd.ops[i + 2].w; a.beta2 = P + nd.ops[i + 2].b; }
+            // ... and the output head behind the norm (the policy's mean / log_std layer): the 512-wide normalised
+            // activation is never written
+            const int lo = out + (two ? 2 : 1);  // buffer index of the last norm's output
+            const int hi = i + (two ? 3 : 2);    // op index that would be the head
+            bool head = false;
+            if (hi < (int)nd.ops.size() && nd.ops[hi].type == OP_HEAD && nd.ops[hi].src == lo && nd.last_use[lo] == hi &&
+                nd.ops[hi].out_dim <= 4) {
+                const Op& ho = nd.ops[hi];
+                a.headW = P + ho.w; a.headB = P + ho.b; a.headOut = c.Y[hi + 1]; a.headN = ho.out_dim;
+                head = true;
+            }
             launch_rowln(a, st);
-            i += two ? 2 : 1;
+            i += (two ? 2 : 1) + (head ? 1 : 0);
             continue;
         }
         if (o.type == OP_LINEAR) {
