@@ -411,6 +411,24 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
             sac.close()
         except Exception as e:
             rep["sac_learner_only"] = {"error": str(e)}
+        # the whole acting pass alone (policy forward on all N observations + Gaussian sample): MFMA utilisation of the
+        # 13 GEMMs together.  MACs per row: embed 10*256, 4 x (256*256 folded attention + 256*512 + 512*256), head
+        # 256*512 + 512*512 + 512*4 (family 1: 10*256 + 256*256 + 256*4)
+        try:
+            from tvc_ai_amd.agent import NativeSAC, sac_cfg
+            sac = NativeSAC(sac_cfg(args.family, batch_size=256, max_act_rows=n), device=device, seed=2)
+            ob, ep = torch.randn(n, 10, device=device), torch.randn(n, 2, device=device)
+            outs = tuple(torch.empty(n, 2, device=device) for _ in range(3))
+            us_a = graph_time_us(lambda k: sac.act(ob, ep, out=outs), 5, device)
+            macs = (10 * 256 + 4 * (256 * 256 + 2 * 256 * 512) + 256 * 512 + 512 * 512 + 512 * 4) if args.family == 0 \
+                else (10 * 256 + 256 * 256 + 256 * 4)
+            tf_a = 2.0 * macs * n / (us_a * 1e-6) / 1e12
+            rep["acting_pass_only"] = {"us_per_call": us_a, "rows": n, "rows_per_s": n / (us_a * 1e-6), "mfma_tflops": tf_a,
+                                       "frac_of_f32_mfma_peak": tf_a / MFMA_F32_PEAK_TF, "flops_per_row": 2.0 * macs}
+            sac.close()
+            del ob, ep, outs
+        except Exception as e:
+            rep["acting_pass_only"] = {"error": str(e)}
         # the reference's default acting path (hierarchical_rl.enabled, agent/...:751-754) for all N envs per call
         try:
             from tvc_ai_amd.hierarchical import HierarchicalPolicy
