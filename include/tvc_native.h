@@ -306,6 +306,12 @@ int tvc_replay_insert(tvc_replay* rb, const float* s, const float* a, const floa
 int tvc_replay_sample(tvc_replay* rb, int32_t batch, uint64_t seed, uint64_t counter, float* s, float* a, float* r,
                       float* s2, float* d, void* stream);
 
+/* Snapshot for a true resume (the reference's --resume is a stub, scripts/train.py:904-907): meta = {head, size, sample
+ * counter}; rows_dev float[size, 2*obs+A+2] in storage order (may be NULL on export to query meta only).  Both calls
+ * synchronise the device. */
+int tvc_replay_export(tvc_replay* rb, float* rows_dev, int64_t meta[3]);
+int tvc_replay_import(tvc_replay* rb, const float* rows_dev, const int64_t meta[3]);
+
 #ifdef __cplusplus
 }
 #endif

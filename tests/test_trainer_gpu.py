@@ -67,3 +67,33 @@ def test_train_loop_with_the_shipped_acting_path():
     assert not torch.equal(p0, tr.sac.params)              # the SAC nets learn ...
     assert torch.equal(low0, tr.hier.low.params)           # ... the acting nets are never trained (as in the reference)
     tr.close()
+
+
+def test_checkpoint_resume_continues_the_same_run(tmp_path):
+    """learner + env SoA state + observations + replay (rows, counters, Philox key) + RNG round-trip: a fresh trainer built with
+    a DIFFERENT seed and loaded from the checkpoint continues like the original (equal to float-atomic summation order)"""
+    from tvc_ai_amd.trainer import VecTrainer
+    kw = dict(family=1, batch_size=64, replay_capacity=4096, overlap=True)
+    a = VecTrainer(256, seed=21, **kw)
+    for _ in range(6):
+        a.step(True)
+    path = str(tmp_path / "resume.pt")
+    a.save_checkpoint(path)
+    for _ in range(5):
+        a.step(True)
+    torch.cuda.synchronize()
+    b = VecTrainer(256, seed=99, **kw)  # different seed: everything that matters must come from the checkpoint
+    b.load_checkpoint(path)
+    assert b.steps == 6 and len(b.rb) == 6 * 256
+    for _ in range(5):
+        b.step(True)
+    torch.cuda.synchronize()
+    assert torch.allclose(a.sac.params, b.sac.params, atol=1e-6, rtol=0)
+    ea, eb = a.env.export_state(), b.env.export_state()
+    assert torch.equal(ea["aux"][:, 0], eb["aux"][:, 0])                       # per-env step counters
+    assert torch.allclose(ea["dyn"], eb["dyn"], atol=1e-5)
+    ra, ma = a.rb.export()
+    rbb, mb = b.rb.export()
+    assert ma == mb and torch.allclose(ra, rbb, atol=1e-5)
+    a.close()
+    b.close()

@@ -103,6 +103,8 @@ SIGNATURES.update({
     "tvc_nn_linear_forward": (C.c_int, [_VP, _VP, _VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP]),
     "tvc_replay_create": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_VP)]),
     "tvc_replay_destroy": (None, [_VP]),
+    "tvc_replay_export": (C.c_int, [_VP, _VP, C.POINTER(C.c_int64)]),
+    "tvc_replay_import": (C.c_int, [_VP, _VP, C.POINTER(C.c_int64)]),
     "tvc_replay_size": (C.c_int64, [_VP]),
     "tvc_replay_insert": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, C.c_int32, _VP]),
     "tvc_replay_sample": (C.c_int, [_VP, C.c_int32, C.c_uint64, C.c_uint64, _VP, _VP, _VP, _VP, _VP, _VP]),

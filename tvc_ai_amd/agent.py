@@ -329,6 +329,20 @@ class ReplayBuffer:
         self.insert(f(obs, self.obs_dim), f(action, self.act_dim), torch.tensor([float(reward)], device=dev),
                     f(next_obs, self.obs_dim), torch.tensor([1 if done else 0], dtype=torch.uint8, device=dev))
 
+    def export(self):
+        """-> (rows[size, 2*obs+A+2] in storage order, [head, size, sample counter]); synchronises (checkpoints only)"""
+        meta = (C.c_int64 * 3)()
+        nat.check(self.L.tvc_replay_export(self._h, None, meta))
+        rows = torch.empty((int(meta[1]), 2 * self.obs_dim + self.act_dim + 2), dtype=torch.float32, device=self.device)
+        nat.check(self.L.tvc_replay_export(self._h, rows.data_ptr() if meta[1] > 0 else None, meta))
+        return rows, [int(meta[0]), int(meta[1]), int(meta[2])]
+
+    def import_(self, rows: torch.Tensor, meta):
+        rows = torch.as_tensor(rows, dtype=torch.float32).to(self.device).contiguous()
+        assert rows.shape[0] == int(meta[1]) and (rows.numel() == 0 or rows.shape[1] == 2 * self.obs_dim + self.act_dim + 2)
+        nat.check(self.L.tvc_replay_import(self._h, rows.data_ptr() if rows.numel() else None,
+                                           (C.c_int64 * 3)(int(meta[0]), int(meta[1]), int(meta[2]))))
+
     def sample(self, batch: int, counter: Optional[int] = None, out=None):
         dev = self.device
         if out is None:

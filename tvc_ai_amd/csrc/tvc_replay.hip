@@ -149,4 +149,30 @@ int tvc_replay_sample(tvc_replay* rb, int32_t batch, uint64_t seed, uint64_t cou
     return 0;
 }
 
+// checkpoint support (synchronous): rows_dev receives / provides the first `size` rows in storage order
+// ({s, a, r, s2, d} x row), meta = {head, size, sample counter}
+int tvc_replay_export(tvc_replay* rb, float* rows_dev, int64_t meta[3]) {
+    if (!rb || !meta) return tvc::set_error(TVC_EINVAL, "null argument");
+    TVC_HIP_CHECK(hipSetDevice(rb->device));
+    TVC_HIP_CHECK(hipDeviceSynchronize());
+    long st[3];
+    TVC_HIP_CHECK(hipMemcpy(st, rb->st, sizeof(st), hipMemcpyDeviceToHost));
+    meta[0] = st[0]; meta[1] = st[1]; meta[2] = st[2];
+    if (rows_dev && st[1] > 0)
+        TVC_HIP_CHECK(hipMemcpy(rows_dev, rb->buf, (size_t)st[1] * (2 * rb->no + rb->na + 2) * sizeof(float), hipMemcpyDeviceToDevice));
+    return 0;
+}
+int tvc_replay_import(tvc_replay* rb, const float* rows_dev, const int64_t meta[3]) {
+    if (!rb || !meta) return tvc::set_error(TVC_EINVAL, "null argument");
+    if (meta[1] < 0 || meta[1] > rb->cap || meta[0] < 0 || meta[0] >= rb->cap || (meta[1] > 0 && !rows_dev))
+        return tvc::set_error(TVC_EINVAL, "snapshot does not fit this buffer (capacity %ld)", rb->cap);
+    TVC_HIP_CHECK(hipSetDevice(rb->device));
+    TVC_HIP_CHECK(hipDeviceSynchronize());
+    if (meta[1] > 0)
+        TVC_HIP_CHECK(hipMemcpy(rb->buf, rows_dev, (size_t)meta[1] * (2 * rb->no + rb->na + 2) * sizeof(float), hipMemcpyDeviceToDevice));
+    long st[3] = {(long)meta[0], (long)meta[1], (long)meta[2]};
+    TVC_HIP_CHECK(hipMemcpy(rb->st, st, sizeof(st), hipMemcpyHostToDevice));
+    return 0;
+}
+
 }  // extern "C"

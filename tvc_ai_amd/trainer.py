@@ -148,6 +148,46 @@ class VecTrainer:
                 sac.update(s, a, r, s2, d, self.eps1[k], self.eps2[k], all_reduce=self.sync, grad_scale=gs)
         main.wait_stream(side)
 
+    # -- true resume (the reference's --resume is a stub, scripts/train.py:904-907): learner, env SoA state, current
+    #    observations, replay contents and counters, and the device RNG state
+    def state_dict(self):
+        torch.cuda.synchronize(self.device)
+        rows, meta = self.rb.export()
+        return {
+            "steps": self.steps, "cur": self.cur,
+            "sac": {"params": self.sac.params.cpu(), "adam_m": self.sac.adam_m.cpu(), "adam_v": self.sac.adam_v.cpu(),
+                    "adam_steps": self.sac.adam_steps()},
+            "env": {k: v.cpu() for k, v in self.env.export_state().items()},
+            "obs": self.obs[self.cur].cpu(), "prev_done": self.prev_done.cpu(),
+            "replay": {"rows": rows.cpu(), "meta": meta, "seed": int(self.rb.seed)},
+            "env_seed": int(self.env.cfg.seed),
+            "rng": torch.cuda.get_rng_state(self.device),
+        }
+
+    def load_state_dict(self, sd):
+        self.steps, self.cur = int(sd["steps"]), int(sd["cur"])
+        self.sac.params.copy_(sd["sac"]["params"])
+        self.sac.adam_m.copy_(sd["sac"]["adam_m"])
+        self.sac.adam_v.copy_(sd["sac"]["adam_v"])
+        self.sac.set_adam_steps(sd["sac"]["adam_steps"])
+        self.sac.sync_derived()
+        self.env.import_state(**sd["env"])
+        self.obs[self.cur].copy_(sd["obs"])
+        self.prev_done.copy_(sd["prev_done"])
+        self.rb.import_(sd["replay"]["rows"], sd["replay"]["meta"])
+        self.rb.seed = int(sd["replay"]["seed"])  # Philox key of the batch draws
+        if int(sd["env_seed"]) != int(self.env.cfg.seed) and int(self.env.cfg.dr_enabled):
+            raise ValueError("domain-randomised envs draw from (seed, env id, episode): build the trainer with the checkpoint's "
+                             f"seed {int(sd['env_seed'])} to resume")
+        torch.cuda.set_rng_state(sd["rng"], self.device)
+        torch.cuda.synchronize(self.device)
+
+    def save_checkpoint(self, path: str):
+        torch.save(self.state_dict(), path)
+
+    def load_checkpoint(self, path: str):
+        self.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+
     def stats(self):
         return {"env_steps": self.steps * self.n, "updates": self.steps * self.updates_per_step,
                 "losses": self.sac.losses.cpu().tolist()}
