@@ -398,7 +398,8 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
         # learner alone (no env stepping): back-to-back SAC updates at B = 256 on a fixed batch
         try:
             from tvc_ai_amd.agent import NativeSAC, sac_cfg
-            sac = NativeSAC(sac_cfg(args.family, batch_size=256, max_act_rows=256), device=device, seed=1)
+            sac = NativeSAC(sac_cfg(args.family, batch_size=256, max_act_rows=256, dropout_p=0.1 if args.family == 0 else 0.0),
+                            device=device, seed=1)
             B = 256
             bt = (torch.randn(B, 10, device=device), torch.rand(B, 2, device=device) * 2 - 1, torch.randn(B, device=device),
                   torch.randn(B, 10, device=device), torch.zeros(B, device=device), torch.randn(B, 2, device=device),
@@ -407,6 +408,7 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
             flops = 4.88e9 if args.family == 0 else 0.565e9  # SURVEY 8d algorithmic minimum per update
             rep["sac_learner_only"] = {"updates_per_s": 1e6 / us_up, "us_per_update": us_up, "batch": B,
                                        "mfma_tflops": flops / (us_up * 1e-6) / 1e12,
+                                       "dropout_in_update": 0.1 if args.family == 0 else 0.0,
                                        "note": "latency-bound at batch 256 (H5): ~100 dependent launches per update"}
             sac.close()
         except Exception as e:

@@ -170,6 +170,12 @@ typedef struct tvc_sac_cfg {
     float adam_b1, adam_b2, adam_eps; /* torch.optim.Adam defaults */
     int32_t use_se;                 /* 1: SqueezeExcitation(d_model, 16) after feature_norm (agent/...:104-118,151-152,214-215): the
                                        NetworkConfig() default of the hierarchical low-level policy; acting only */
+    float dropout_p;                /* 0 (default): nets as in .eval(), what the goldens pin.  0.1 = the reference's train-mode
+                                       update (it never calls .eval()): Dropout after the LayerNorms of the policy head and the
+                                       critics, and the encoder layers' attention-weight / dropout1 / FFN / dropout2 sites, in
+                                       every forward of tvc_sac_update (family 0).  Masks are a counter-based hash, not torch's
+                                       Philox stream: statistically equivalent.  tvc_sac_act stays deterministic. */
+    int32_t nhead;                  /* 8: attention heads (only the granularity of the attention-weight dropout at seq len 1) */
 } tvc_sac_cfg;
 
 void tvc_sac_default_cfg(tvc_sac_cfg* cfg, int32_t family);

@@ -35,9 +35,45 @@ def _ln(x, P, name, eps=1e-5):
     return F.layer_norm(x, (x.shape[-1],), P[name + ".weight"], P[name + ".bias"], eps)
 
 
-def actor_forward(P, obs, batch_pe=False, n_layers=4):
+class DropMasks:
+    """The counter-hash dropout masks of the HIP kernels (tvc_nn_kernels.h: drop_mix / drop_key / drop_factor) restated with
+    numpy, so that a train-mode update can be compared mask for mask.  p = thresh / 65536; kept values scale by 1 / (1 - p)."""
+
+    def __init__(self, p):
+        self.thresh = int(round(p * 65536.0))
+        self.scale = np.float32(65536.0) / np.float32(65536 - self.thresh)
+
+    @staticmethod
+    def _mix(x):
+        m = np.uint64(0xFFFFFFFF)
+        x = x & m
+        x ^= x >> np.uint64(16)
+        x = (x * np.uint64(0x85EBCA6B)) & m
+        x ^= x >> np.uint64(13)
+        x = (x * np.uint64(0xC2B2AE35)) & m
+        x ^= x >> np.uint64(16)
+        return x
+
+    def factor(self, ctr, site, z, row0, rows, cols, group=1):
+        m = np.uint64(0xFFFFFFFF)
+        key = self._mix(np.uint64(ctr) ^ ((np.uint64(site) * np.uint64(0x9E3779B9)) & m) ^ ((np.uint64(z) * np.uint64(0x7F4A7C15)) & m))
+        r = self._mix((np.arange(row0, row0 + rows, dtype=np.uint64) + np.uint64(0x632BE5AB)) & m)[:, None]
+        c = (np.arange(cols, dtype=np.uint64) // np.uint64(group))[None, :]
+        x = self._mix(key ^ r ^ (((c >> np.uint64(1)) * np.uint64(0x9E3779B1)) & m))
+        b = np.where((c & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xFFFF))
+        return torch.from_numpy(np.where(b >= self.thresh, self.scale, np.float32(0.0)).astype(np.float32))
+
+    def hook(self, ctr, site_base, z=0, row0=0):
+        """-> drop(op_index, x, group): x * mask for the forward call identified by (ctr, site_base, z, row0)"""
+        return lambda op, x, group=1: x * self.factor(ctr, site_base + op, z, row0, x.shape[0], x.shape[1], group).to(x)
+
+
+def actor_forward(P, obs, batch_pe=False, n_layers=4, drop=None, nhead=8):
     """-> mean[B,A], log_std[B,A] (clamped to [-20, 2]).  batch_pe=True reproduces the reference's
-    row-indexed positional encoding (row b gets PE(b)); False = PE(0) on every row (== reference at B=1)."""
+    row-indexed positional encoding (row b gets PE(b)); False = PE(0) on every row (== reference at B=1).
+    drop(op_index, x, group): train-mode dropout hook (DropMasks.hook); op indices follow the native net."""
+    if drop is None:
+        drop = lambda op, x, group=1: x
     d = P["input_embedding.weight"].shape[0]
     x = obs @ P["input_embedding.weight"].T + P["input_embedding.bias"]
     pe = positional_encoding(obs.shape[0] if batch_pe else 1, d).to(obs)
@@ -46,27 +82,30 @@ def actor_forward(P, obs, batch_pe=False, n_layers=4):
         pre = f"transformer_encoder.layers.{l}."
         Wv = P[pre + "self_attn.in_proj_weight"][2 * d:3 * d]
         bv = P[pre + "self_attn.in_proj_bias"][2 * d:3 * d]
-        v = x @ Wv.T + bv
-        a = v @ P[pre + "self_attn.out_proj.weight"].T + P[pre + "self_attn.out_proj.bias"]
+        v = drop(1 + 6 * l, x @ Wv.T + bv, d // nhead)  # attention-weight dropout at one key: a whole head of V
+        a = drop(2 + 6 * l, v @ P[pre + "self_attn.out_proj.weight"].T + P[pre + "self_attn.out_proj.bias"])
         x = _ln(x + a, P, pre + "norm1")
-        f = F.gelu(x @ P[pre + "linear1.weight"].T + P[pre + "linear1.bias"])
-        f = f @ P[pre + "linear2.weight"].T + P[pre + "linear2.bias"]
+        f = drop(4 + 6 * l, F.gelu(x @ P[pre + "linear1.weight"].T + P[pre + "linear1.bias"]))
+        f = drop(5 + 6 * l, f @ P[pre + "linear2.weight"].T + P[pre + "linear2.bias"])
         x = _ln(x + f, P, pre + "norm2")
+    base = 1 + 6 * n_layers
     x = _ln(x, P, "feature_norm")
     if "se_block.fc1.weight" in P:  # SqueezeExcitation (agent/...:104-118): pooling a [B, C, 1] tensor over its last axis is the identity
         y = F.relu(x @ P["se_block.fc1.weight"].T + P["se_block.fc1.bias"])
         x = x * torch.sigmoid(y @ P["se_block.fc2.weight"].T + P["se_block.fc2.bias"])
-    h = _ln(F.gelu(x @ P["policy_head.0.weight"].T + P["policy_head.0.bias"]), P, "policy_head.2")
-    h = _ln(F.gelu(h @ P["policy_head.4.weight"].T + P["policy_head.4.bias"]), P, "policy_head.6")
+    h = drop(base + 2, _ln(F.gelu(x @ P["policy_head.0.weight"].T + P["policy_head.0.bias"]), P, "policy_head.2"))
+    h = drop(base + 4, _ln(F.gelu(h @ P["policy_head.4.weight"].T + P["policy_head.4.bias"]), P, "policy_head.6"))
     out = h @ P["policy_head.8.weight"].T + P["policy_head.8.bias"]
     a_dim = out.shape[1] // 2
     return out[:, :a_dim], torch.clamp(out[:, a_dim:], -20, 2)
 
 
-def critic_forward(Q, s, a):
+def critic_forward(Q, s, a, drop=None):
+    if drop is None:
+        drop = lambda op, x, group=1: x
     x = torch.cat([s, a], -1)
-    h = _ln(F.gelu(x @ Q["0.weight"].T + Q["0.bias"]), Q, "2")
-    h = _ln(F.gelu(h @ Q["4.weight"].T + Q["4.bias"]), Q, "6")
+    h = drop(1, _ln(F.gelu(x @ Q["0.weight"].T + Q["0.bias"]), Q, "2"))
+    h = drop(3, _ln(F.gelu(h @ Q["4.weight"].T + Q["4.bias"]), Q, "6"))
     return (h @ Q["8.weight"].T + Q["8.bias"]).squeeze(-1)
 
 
@@ -107,9 +146,17 @@ class AdamState:
 class SacOracle:
     """State of one SAC learner in reference parameterisation."""
 
-    def __init__(self, policy, q1, q2, batch_pe=False, actor_fn=None, critic_fn=None):
-        self.actor_fn = actor_fn or (lambda P, x: actor_forward(P, x, batch_pe))
-        self.critic_fn = critic_fn or critic_forward
+    def __init__(self, policy, q1, q2, batch_pe=False, actor_fn=None, critic_fn=None, dropout_p=0.0):
+        """dropout_p > 0: the reference's train-mode update with the HIP kernels' masks (DropMasks); site bases as in
+        tvc_sac.hip: actor 0 (rows of s' offset by the batch size: one stacked forward), critics 120 / 140 / 160."""
+        self.masks = DropMasks(dropout_p) if dropout_p > 0 else None
+        self.updates = 0
+        if self.masks is None:
+            self.actor_fn = actor_fn or (lambda P, x, row0=0: actor_forward(P, x, batch_pe))
+            self.critic_fn = critic_fn or (lambda Q, s, a, call=0, z=0: critic_forward(Q, s, a))
+        else:
+            self.actor_fn = lambda P, x, row0=0: actor_forward(P, x, batch_pe, drop=self.masks.hook(self.updates, 0, 0, row0))
+            self.critic_fn = lambda Q, s, a, call=0, z=0: critic_forward(Q, s, a, drop=self.masks.hook(self.updates, 100 + 20 * call, z))
         self.P = {k: v.clone().requires_grad_(True) for k, v in policy.items()}
         self.Q = [{k: v.clone().requires_grad_(True) for k, v in q.items()} for q in (q1, q2)]
         self.TQ = [{k: v.clone() for k, v in q.items()} for q in (q1, q2)]
@@ -119,14 +166,16 @@ class SacOracle:
 
     def update(self, s, a, r, s2, d, eps_next, eps_new):
         """One _update_sac (agent/...:950-1016) with the two Gaussian draws supplied."""
+        fancy = self.masks is not None
+        kw = (lambda call, z: dict(call=call, z=z)) if fancy else (lambda call, z: {})
         with torch.no_grad():
-            m2, ls2 = self.actor_fn(self.P, s2)
+            m2, ls2 = self.actor_fn(self.P, s2, s.shape[0]) if fancy else self.actor_fn(self.P, s2)
             a2 = m2 + torch.exp(ls2) * eps_next
-            tq = torch.min(self.critic_fn(self.TQ[0], s2, a2), self.critic_fn(self.TQ[1], s2, a2))
+            tq = torch.min(self.critic_fn(self.TQ[0], s2, a2, **kw(1, 0)), self.critic_fn(self.TQ[1], s2, a2, **kw(1, 1)))
             y = r + GAMMA * (1 - d) * tq
         losses = []
         for i in range(2):
-            q = self.critic_fn(self.Q[i], s, a)
+            q = self.critic_fn(self.Q[i], s, a, **kw(2, i))
             loss = F.mse_loss(q, y)
             grads = torch.autograd.grad(loss, list(self.Q[i].values()))
             self.opt_q[i].step(self.Q[i], dict(zip(self.Q[i].keys(), grads)))
@@ -135,7 +184,7 @@ class SacOracle:
         std = torch.exp(ls)
         a_new = mean + std * eps_new
         logp = (-((a_new - mean) ** 2) / (2 * std ** 2) - ls - math.log(math.sqrt(2 * math.pi))).sum(-1)
-        qn = torch.min(self.critic_fn(self.Q[0], s, a_new), self.critic_fn(self.Q[1], s, a_new))
+        qn = torch.min(self.critic_fn(self.Q[0], s, a_new, **kw(3, 0)), self.critic_fn(self.Q[1], s, a_new, **kw(3, 1)))
         ploss = -(qn - ALPHA * logp).mean()
         names = list(self.P.keys())
         grads = torch.autograd.grad(ploss, [self.P[k] for k in names], allow_unused=True)
@@ -144,6 +193,7 @@ class SacOracle:
             for i in range(2):
                 for k in self.TQ[i]:
                     self.TQ[i][k].copy_(TAU * self.Q[i][k] + (1 - TAU) * self.TQ[i][k])
+        self.updates += 1
         return losses[0], losses[1], float(ploss.detach())
 
 

@@ -275,9 +275,12 @@ def test_checkpoint_layout_and_round_trip(tmp_path):
     assert b.sac.adam_steps() == [3, 3]
 
 
-def test_gradients_match_autograd_of_the_restatement():
+@pytest.mark.parametrize("dropout_p", [0.0, 0.1])
+def test_gradients_match_autograd_of_the_restatement(dropout_p):
     """the backward kernels on their own: grads after tvc_sac_critic_grads / tvc_sac_actor_grads vs torch.autograd of the
-    oracle's losses (same parameters, batch and noise), before any optimiser step can blur the comparison"""
+    oracle's losses (same parameters, batch and noise), before any optimiser step can blur the comparison.
+    dropout_p = 0.1: the reference's train-mode update; the oracle applies the kernels' own hash masks (DropMasks), so the
+    comparison stays element for element; a second update checks that the masks move on with the update counter."""
     from tvc_ai_amd.agent import NativeSAC, sac_cfg, _ref_to_native_name
     torch.set_num_threads(8)
     rec = _recipe()
@@ -285,13 +288,14 @@ def test_gradients_match_autograd_of_the_restatement():
     rng = np.random.default_rng(meta["seed"])
     nets = ref_nets(rec, meta, rng)
     B = 256
-    sac = NativeSAC(sac_cfg(0, batch_size=B, max_act_rows=B), init=False)
+    sac = NativeSAC(sac_cfg(0, batch_size=B, max_act_rows=B, dropout_p=dropout_p), init=False)
     load_into_native(sac, nets)
     s, a, r, s2, d = [torch.from_numpy(x) for x in rec.make_batch(rng)]
     e1 = torch.from_numpy(rng.standard_normal((B, 2)).astype(np.float32))
     e2 = torch.from_numpy(rng.standard_normal((B, 2)).astype(np.float32))
     sg, ag, rg, s2g, dg, e1g, e2g = cuda(s, a, r, s2, d, e1, e2)
-    orc = st.SacOracle(nets["policy"], nets["q1"], nets["q2"], batch_pe=False)
+    orc = st.SacOracle(nets["policy"], nets["q1"], nets["q2"], batch_pe=False, dropout_p=dropout_p)
+    kw = (lambda call, z: dict(call=call, z=z)) if dropout_p > 0 else (lambda call, z: {})
 
     def close(got, want, what):
         scale = want.abs().max().item()
@@ -301,16 +305,20 @@ def test_gradients_match_autograd_of_the_restatement():
     # critic phase
     sac.critic_grads(sg, ag, rg, s2g, dg, e1g)
     with torch.no_grad():
-        m2, ls2 = orc.actor_fn(orc.P, s2)
+        m2, ls2 = orc.actor_fn(orc.P, s2, B) if dropout_p > 0 else orc.actor_fn(orc.P, s2)
         a2 = m2 + torch.exp(ls2) * e1
-        y = r + st.GAMMA * (1 - d) * torch.min(orc.critic_fn(orc.TQ[0], s2, a2), orc.critic_fn(orc.TQ[1], s2, a2))
+        y = r + st.GAMMA * (1 - d) * torch.min(orc.critic_fn(orc.TQ[0], s2, a2, **kw(1, 0)),
+                                               orc.critic_fn(orc.TQ[1], s2, a2, **kw(1, 1)))
+    q_losses = []
     for i, net in enumerate(("q1", "q2")):
-        loss = torch.nn.functional.mse_loss(orc.critic_fn(orc.Q[i], s, a), y)
+        loss = torch.nn.functional.mse_loss(orc.critic_fn(orc.Q[i], s, a, **kw(2, i)), y)
+        q_losses.append(float(loss.detach()))
         keys = list(orc.Q[i].keys())
         grads = torch.autograd.grad(loss, [orc.Q[i][k] for k in keys])
         for k, gr in zip(keys, grads):
             close(sac.grad_view(f"{net}.{k}").reshape(gr.shape), gr, f"{net}.{k}")
         orc.opt_q[i].step(orc.Q[i], dict(zip(keys, grads)))
+    np.testing.assert_allclose(sac.losses[:2].cpu().numpy(), q_losses, rtol=2e-4)
     sac.critic_apply()
     # actor phase (through the UPDATED critics, data gradients only)
     sac.actor_grads(sg, e2g)
@@ -318,7 +326,8 @@ def test_gradients_match_autograd_of_the_restatement():
     std = torch.exp(ls)
     a_new = mean + std * e2
     logp = (-((a_new - mean) ** 2) / (2 * std ** 2) - ls - np.log(np.sqrt(2 * np.pi))).sum(-1)
-    ploss = -(torch.min(orc.critic_fn(orc.Q[0], s, a_new), orc.critic_fn(orc.Q[1], s, a_new)) - st.ALPHA * logp).mean()
+    ploss = -(torch.min(orc.critic_fn(orc.Q[0], s, a_new, **kw(3, 0)), orc.critic_fn(orc.Q[1], s, a_new, **kw(3, 1)))
+              - st.ALPHA * logp).mean()
     names = list(orc.P.keys())
     grads = torch.autograd.grad(ploss, [orc.P[k] for k in names], allow_unused=True)
     dm, checked = sac.cfg.d_model, 0
@@ -332,6 +341,24 @@ def test_gradients_match_autograd_of_the_restatement():
         close(sac.grad_view(name).reshape(gr.shape), gr, name)
         checked += 1
     assert checked >= 60
+    np.testing.assert_allclose(sac.losses[2].item(), float(ploss.detach()), rtol=2e-4)
+    if dropout_p > 0:
+        # finish the update on both sides, then a whole second update: new masks (the counter moved), same agreement
+        sac.actor_apply()
+        orc.opt_p.step(orc.P, dict(zip(names, grads)))
+        with torch.no_grad():
+            for i in range(2):
+                for k in orc.TQ[i]:
+                    orc.TQ[i][k].copy_(st.TAU * orc.Q[i][k] + (1 - st.TAU) * orc.TQ[i][k])
+        orc.updates += 1
+        first = sac.losses[:3].cpu().numpy().copy()
+        want = orc.update(s, a, r, s2, d, e1, e2)
+        got = sac.update(sg, ag, rg, s2g, dg, e1g, e2g)[:3].cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=5e-4)
+        assert not np.allclose(got, first, rtol=1e-3)
+        # and the masks do what dropout does: about p of the activations are zeroed
+        f = st.DropMasks(dropout_p).factor(3, 7, 0, 0, 512, 512)
+        assert abs((f == 0).float().mean().item() - dropout_p) < 0.01 and abs(f.mean().item() - 1.0) < 0.01
     sac.close()
 
 

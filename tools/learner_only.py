@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs K SAC updates on a fixed batch (no envs) so a kernel trace shows the learner alone.
-usage: rocprofv3 --kernel-trace --output-format csv -d OUT -- python3 tools/learner_only.py [K] [family]"""
+usage: rocprofv3 --kernel-trace --output-format csv -d OUT -- python3 tools/learner_only.py [K] [family] [dropout_p]"""
 import os
 import sys
 
@@ -11,9 +11,10 @@ from tvc_ai_amd.agent import NativeSAC, sac_cfg
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 family = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+dropout = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 B = 256
 d = torch.device("cuda:0")
-sac = NativeSAC(sac_cfg(family, batch_size=B, max_act_rows=B), device=d, seed=1)
+sac = NativeSAC(sac_cfg(family, batch_size=B, max_act_rows=B, dropout_p=dropout), device=d, seed=1)
 g = torch.Generator(device=d).manual_seed(0)
 s, s2 = torch.randn((B, 10), device=d, generator=g), torch.randn((B, 10), device=d, generator=g)
 a = torch.rand((B, 2), device=d, generator=g) * 2 - 1

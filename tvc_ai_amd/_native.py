@@ -66,6 +66,7 @@ class SacCfg(C.Structure):
         ("batch_size", C.c_int32), ("max_act_rows", C.c_int32), ("pe_rows", C.c_int32),
         ("gamma", C.c_float), ("alpha", C.c_float), ("tau", C.c_float), ("lr", C.c_float),
         ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("use_se", C.c_int32),
+        ("dropout_p", C.c_float), ("nhead", C.c_int32),
     ]
 
 

@@ -382,7 +382,11 @@ class MultiAlgorithmAgent:
         cfg = sac_cfg(family, obs_dim=obs_dim, act_dim=action_dim, d_model=int(tr.get("d_model", 256)),
                       n_layers=int(tr.get("num_layers", 4)), ff_dim=int(tr.get("dim_feedforward", 512)),
                       head1=int(hd[0]), head2=int(hd[1]), batch_size=self.batch_size,
-                      max_act_rows=int(native.get("max_act_rows", 4096)), pe_rows=int(native.get("pe_rows", 1)))
+                      max_act_rows=int(native.get("max_act_rows", 4096)), pe_rows=int(native.get("pe_rows", 1)),
+                      nhead=int(tr.get("nhead", 8)),
+                      # the reference never calls .eval(): its update runs with Dropout active (network.transformer.dropout for
+                      # the policy, a hard-coded 0.1 in the critics, agent/...:457,596-604); one value drives both here
+                      dropout_p=float(native.get("dropout", tr.get("dropout", 0.1))) if family == 0 else 0.0)
         self.sac = NativeSAC(cfg, device=self.device, seed=seed)
         self.algorithms = {"sac": {"type": "sac", "native": self.sac}}
         self.algorithm_weights = {"sac": 1.0}

@@ -27,6 +27,32 @@ __device__ __forceinline__ float act_grad(float z, int act) {
     return act == ACT_GELU ? gelu_grad(z) : (act == ACT_RELU ? (z > 0.0f ? 1.0f : 0.0f) : 1.0f);
 }
 
+// ------------------------------------------------------------------ dropout (update path only)
+// nn.Dropout(p) of the reference's train-mode nets (agent/multi_algorithm_agent.py:141,159,163,600,604 and the encoder
+// layers' dropout / dropout1 / dropout2 / attention-weight dropout).  torch's Philox stream cannot be reproduced, so the
+// masks are a hash of (update counter, site, group, row, column): statistically equivalent, regenerated in the backward
+// instead of stored.  p = thresh / 65536, kept values are scaled by 1 / (1 - p).
+struct DropArgs {
+    const int* ctr;   // device-resident update counter (the actor's Adam step count); nullptr = no dropout
+    unsigned site;    // identifies the masked tensor and the forward call it belongs to
+    unsigned thresh;  // an element is dropped when its 16 hash bits are < thresh
+    float scale;
+    int group;        // columns sharing one mask element: 1 = elementwise, d_model / nhead = one per attention head
+};
+__device__ __forceinline__ unsigned drop_mix(unsigned x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned drop_key(const DropArgs& d, unsigned z) {
+    return drop_mix((unsigned)(*d.ctr) ^ (d.site * 0x9E3779B9u) ^ (z * 0x7F4A7C15u));
+}
+__device__ __forceinline__ float drop_factor(const DropArgs& d, unsigned key, int row, int col) {
+    const unsigned c = (unsigned)col / (unsigned)d.group;
+    const unsigned x = drop_mix(key ^ drop_mix((unsigned)row + 0x632BE5ABu) ^ ((c >> 1) * 0x9E3779B1u));
+    const unsigned b = (c & 1u) ? (x >> 16) : (x & 0xFFFFu);
+    return b >= d.thresh ? d.scale : 0.0f;
+}
+
 // ------------------------------------------------------------------ GEMM  C[M,N] = epi(sum_k A(m,k) * B(n,k))
 struct GemmArgs {
     const float* A;   // A_KC: A[m*lda + k]   else A[k*lda + m]
@@ -46,6 +72,8 @@ struct GemmArgs {
     float* colsum;          // atomic column sums of the final output (bias gradient)
     // per-group element strides (blockIdx.z)
     long gA, gA2, gB, gC, gBias, gZ, gR, gDZ, gCol;
+    DropArgs drop;          // forward: dropout on act(.) before the residual add   (split-K kernel only)
+    DropArgs dmask;         // dgrad: the producer's dropout mask, applied before its act' (split-K kernel only)
 };
 
 constexpr int GBM = 64, GBN = 64, GBK = 16, GLD = GBK + 4;  // LDS rows padded to 20 floats (16-B aligned)
@@ -254,6 +282,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 // ---- shared epilogue: bias, row table, pre-activation copy, activation, residual, act' multiply
 struct GemmEpi {
     float* C; const float* bias; float* Zout; const float* Radd; const float* dZ; float* colsum;
+    unsigned kdrop, kmask;  // per-launch dropout hash keys
 };
 __device__ __forceinline__ GemmEpi gemm_epi_ptrs(const GemmArgs& g, long z) {
     GemmEpi e;
@@ -263,6 +292,8 @@ __device__ __forceinline__ GemmEpi gemm_epi_ptrs(const GemmArgs& g, long z) {
     e.Radd = g.Radd ? g.Radd + z * g.gR : nullptr;
     e.dZ = g.dactZ ? g.dactZ + z * g.gDZ : nullptr;
     e.colsum = g.colsum ? g.colsum + z * g.gCol : nullptr;
+    e.kdrop = g.drop.ctr ? drop_key(g.drop, (unsigned)z) : 0u;
+    e.kmask = g.dmask.ctr ? drop_key(g.dmask, (unsigned)z) : 0u;
     return e;
 }
 __device__ __forceinline__ float gemm_epi_value(const GemmArgs& g, const GemmEpi& e, float acc, int row, int col) {
@@ -271,7 +302,9 @@ __device__ __forceinline__ float gemm_epi_value(const GemmArgs& g, const GemmEpi
     const long o = (long)row * g.ldc + col;
     if (e.Zout) e.Zout[o] = v;
     v = act_f(v, g.act);
+    if (g.drop.ctr) v *= drop_factor(g.drop, e.kdrop, row, col);
     if (e.Radd) v += e.Radd[o];
+    if (g.dmask.ctr) v *= drop_factor(g.dmask, e.kmask, row, col);
     if (e.dZ) v *= act_grad(e.dZ[o], g.dact);
     return v;
 }
@@ -730,6 +763,7 @@ struct LnArgs {
     float* mean; float* rstd;  // [M] saved for backward (may be null)
     int M, N;                  // N in {256, 512} (multiple of 256 handled as N/64 floats per lane, <= 8)
     long gX, gY, gP, gS;       // group strides: activations, params, stats
+    DropArgs drop;             // dropout on the normalised output (policy head / critics: Linear-GELU-LN-Dropout)
 };
 template <int VPL>  // values per lane = N / 64
 __global__ void __launch_bounds__(256) layernorm_fwd_kernel(LnArgs a) {
@@ -767,6 +801,11 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(LnArgs a) {
         o.y = (v[i + 1] - mean) * rstd * gg.y + bb.y;
         o.z = (v[i + 2] - mean) * rstd * gg.z + bb.z;
         o.w = (v[i + 3] - mean) * rstd * gg.w + bb.w;
+        if (a.drop.ctr) {
+            const unsigned key = drop_key(a.drop, (unsigned)z);
+            o.x *= drop_factor(a.drop, key, row, c); o.y *= drop_factor(a.drop, key, row, c + 1);
+            o.z *= drop_factor(a.drop, key, row, c + 2); o.w *= drop_factor(a.drop, key, row, c + 3);
+        }
         *reinterpret_cast<float4*>(y + c) = o;
     }
     if (lane == 0 && a.mean) {
@@ -825,6 +864,9 @@ struct LnBwdArgs {
     float* colsum;              // optional [N]
     int M, N;
     long gA, gP, gS;            // strides: activations (dY, X, dX, Zp), params (gamma, dgamma, dbeta, colsum), stats
+    DropArgs dmask;             // this LayerNorm's output dropout: the incoming dY is masked first
+    float* dXm; DropArgs omask; // optional second output dX * mask: the dZ of a producing Linear whose (dropped) output was
+                                // added to a residual (dX itself stays unmasked for the residual path)
 };
 template <int VPL>
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(LnBwdArgs a) {
@@ -852,7 +894,13 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(LnBwdArgs a) {
             const int c = (i / 4) * 256 + lane * 4;
             const float4 xv = *reinterpret_cast<const float4*>(a.X + off + c);
             const float4 dv = *reinterpret_cast<const float4*>(a.dY + off + c);
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+            if (a.dmask.ctr) {
+                const unsigned key = drop_key(a.dmask, (unsigned)z);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ds[j] *= drop_factor(a.dmask, key, row, c + j);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 xh[i + j] = (xs[j] - mean) * rstd;
@@ -877,9 +925,15 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(LnBwdArgs a) {
                 o4[0] *= act_grad(zv.x, a.dact); o4[1] *= act_grad(zv.y, a.dact);
                 o4[2] *= act_grad(zv.z, a.dact); o4[3] *= act_grad(zv.w, a.dact);
             }
+            *reinterpret_cast<float4*>(a.dX + off + c) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            if (a.dXm) {  // the producing Linear's bias sits inside its dropout: its gradient sums the MASKED values
+                const unsigned key = drop_key(a.omask, (unsigned)z);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o4[j] *= drop_factor(a.omask, key, row, c + j);
+                *reinterpret_cast<float4*>(a.dXm + off + c) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) cs[i + j] += o4[j];
-            *reinterpret_cast<float4*>(a.dX + off + c) = make_float4(o4[0], o4[1], o4[2], o4[3]);
         }
     }
     // column sums (dgamma, dbeta, bias gradient of the producing Linear): the four waves are reduced through LDS

@@ -23,6 +23,7 @@ struct Op {
     int type, in_dim, out_dim, act, src, res, rowtab;
     int ext = 0;  // 1: weight/bias offsets address the derived-weights buffer (folded W_o W_v of the acting net)
     int mul = -1;  // buffer multiplied into the output after the activation (SqueezeExcitation gate); thin layers only
+    int drop = 0;  // train-mode dropout on this op's output: 0 none, 1 elementwise, g > 1 one mask per g columns (attention head)
     long w, b;  // offsets inside the net's parameter block (LINEAR/HEAD: weight[out,in], bias[out]; LN: gamma, beta)
 };
 struct TensorInfo { std::string name; long off; int rows, cols; };
@@ -72,11 +73,17 @@ static NetDef build_actor(const tvc_sac_cfg& c) {
         int x = n.add(OP_LINEAR, "input_embedding", c.obs_dim, d, ACT_NONE, 0, -1, 1);
         for (int l = 0; l < c.n_layers; ++l) {
             const std::string p = "layers." + std::to_string(l) + ".";
+            // dropout sites of nn.TransformerEncoderLayer at sequence length 1: attention weights (softmax over one key = 1,
+            // so the mask zeroes / rescales a whole head of V), dropout1, the FFN's dropout, dropout2
             int v = n.add(OP_LINEAR, p + "v_proj", d, d, ACT_NONE, x, -1, 0);
+            n.ops.back().drop = std::max(1, d / std::max(1, (int)c.nhead));
             int a = n.add(OP_LINEAR, p + "out_proj", d, d, ACT_NONE, v, x, 0);
+            n.ops.back().drop = 1;
             int x1 = n.add(OP_LN, p + "norm1", d, d, 0, a, -1, 0);
             int f = n.add(OP_LINEAR, p + "linear1", d, c.ff_dim, ACT_GELU, x1, -1, 0);
+            n.ops.back().drop = 1;
             int g = n.add(OP_LINEAR, p + "linear2", c.ff_dim, d, ACT_NONE, f, x1, 0);
+            n.ops.back().drop = 1;
             x = n.add(OP_LN, p + "norm2", d, d, 0, g, -1, 0);
         }
         x = n.add(OP_LN, "feature_norm", d, d, 0, x, -1, 0);
@@ -88,8 +95,10 @@ static NetDef build_actor(const tvc_sac_cfg& c) {
         }
         x = n.add(OP_LINEAR, "policy_head.0", d, c.head1, ACT_GELU, x, -1, 0);
         x = n.add(OP_LN, "policy_head.2", c.head1, c.head1, 0, x, -1, 0);
+        n.ops.back().drop = 1;
         x = n.add(OP_LINEAR, "policy_head.4", c.head1, c.head2, ACT_GELU, x, -1, 0);
         x = n.add(OP_LN, "policy_head.6", c.head2, c.head2, 0, x, -1, 0);
+        n.ops.back().drop = 1;
         n.add(OP_HEAD, "policy_head.8", c.head2, 2 * c.act_dim, 0, x, -1, 0);
     } else {
         int x = n.add(OP_LINEAR, "0", c.obs_dim, c.mlp1, ACT_RELU, 0, -1, 0);
@@ -143,8 +152,10 @@ static NetDef build_critic(const tvc_sac_cfg& c) {
     if (c.family == 0) {
         int x = n.add(OP_LINEAR, "0", n.in_dim, c.critic1, ACT_GELU, 0, -1, 0);
         x = n.add(OP_LN, "2", c.critic1, c.critic1, 0, x, -1, 0);
+        n.ops.back().drop = 1;
         x = n.add(OP_LINEAR, "4", c.critic1, c.critic2, ACT_GELU, x, -1, 0);
         x = n.add(OP_LN, "6", c.critic2, c.critic2, 0, x, -1, 0);
+        n.ops.back().drop = 1;
         n.add(OP_HEAD, "8", c.critic2, 1, 0, x, -1, 0);
     } else {
         int x = n.add(OP_LINEAR, "0", n.in_dim, c.critic1, ACT_RELU, 0, -1, 0);
@@ -172,6 +183,9 @@ static int validate(const tvc_sac_cfg* c) {
     if (c->batch_size < 1 || c->max_act_rows < 1) return tvc::set_error(TVC_EINVAL, "batch_size / max_act_rows must be >= 1");
     if (c->pe_rows < 1) return tvc::set_error(TVC_EINVAL, "pe_rows must be >= 1");
     if (c->use_se != 0 && c->use_se != 1) return tvc::set_error(TVC_EINVAL, "use_se must be 0 or 1");
+    if (!(c->dropout_p >= 0.0f && c->dropout_p < 0.9f)) return tvc::set_error(TVC_EINVAL, "dropout_p must be in [0, 0.9)");
+    if (c->dropout_p > 0.0f && c->family != 0) return tvc::set_error(TVC_EINVAL, "dropout_p needs family 0 (the MLP family has no dropout)");
+    if (c->family == 0 && (c->nhead < 1 || (c->d_model % c->nhead) != 0)) return tvc::set_error(TVC_EINVAL, "nhead must divide d_model");
     if (c->use_se && (c->family != 0 || c->d_model != 256)) return tvc::set_error(TVC_EINVAL, "use_se needs family 0, d_model 256");
     return 0;
 }
@@ -180,6 +194,7 @@ static int validate(const tvc_sac_cfg* c) {
 struct Ctx {
     int M = 0, G = 1;
     std::vector<float*> Y, dY, Z, mean, rstd;  // per buffer index
+    std::vector<float*> dYm;  // masked copy of dY for a Linear whose dropped output fed a residual add (dropout on)
     std::vector<long> gY;                       // group stride (elements) per buffer
 };
 
@@ -193,7 +208,8 @@ static void launch_gemm(bool a_kc, bool b_kc, const GemmArgs& g, int G, hipStrea
     const bool aligned = ((g.lda & 3) == 0) && ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
     const int fv = g_force_variant;
-    if ((fv == 3 || (fv == 0 && (long)g.M * g.N <= 512L * 512L)) && g.A2 == nullptr) {
+    const bool dropping = g.drop.ctr != nullptr || g.dmask.ctr != nullptr;  // only the split-K kernel's epilogue knows the masks
+    if ((fv == 3 || dropping || (fv == 0 && (long)g.M * g.N <= 512L * 512L)) && g.A2 == nullptr) {
         // update path (batch of a few hundred rows): latency-optimised split-K kernel
         dim3 grid((g.N + 31) / 32, (g.M + 31) / 32, G), block(256);
         const bool fast = aligned && (g.M % 32) == 0 && (g.N % 32) == 0 && (g.K % 16) == 0 &&
@@ -238,7 +254,8 @@ static void launch_gemm_bwd_pair(const GemmArgs& w, const GemmArgs& x, int G, hi
     auto fast = [](const GemmArgs& g) {
         return ((g.lda & 3) == 0) && ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
                ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) && (g.M % 32) == 0 && (g.N % 32) == 0 && (g.K % 16) == 0 &&
-               ((g.gA | g.gB) & 3) == 0 && g.A2 == nullptr && (long)g.M * g.N <= 512L * 512L;
+               ((g.gA | g.gB) & 3) == 0 && g.A2 == nullptr &&
+               ((long)g.M * g.N <= 512L * 512L || g.drop.ctr != nullptr || g.dmask.ctr != nullptr);
     };
     if (g_force_variant != 0 || !fast(w) || !fast(x)) {
         launch_gemm(false, false, w, G, st);
@@ -265,9 +282,19 @@ static ThinArgs thin_input(const Op& o, const float* X, long gX, const In2* in2,
 }
 static bool thin_ok(const Op& o) { return o.type == OP_LINEAR && o.in_dim <= THIN_K && o.res < 0; }
 
+// train-mode dropout of one forward call (and of the backward that follows it): the counter, p, and the site base that
+// tells this call's masks from every other call's
+struct DropCtl { const int* ctr; unsigned thresh; float scale; unsigned site_base; };
+static DropArgs drop_args(const DropCtl* dc, int op_index, int group) {
+    DropArgs d{};
+    if (dc && group > 0) { d.ctr = dc->ctr; d.site = dc->site_base + (unsigned)op_index; d.thresh = dc->thresh; d.scale = dc->scale; d.group = group; }
+    return d;
+}
+
 // forward of one net (G parameter groups batched through blockIdx.z).  X: [G?][M,in]; gX = 0 shares one input.
 static void net_forward(const NetDef& nd, const float* P, long gP, const float* X, long gX, int M, int G, Ctx& c, bool save,
-                        const float* pe, int pe_rows, hipStream_t st, const float* Pext = nullptr, const In2* in2 = nullptr) {
+                        const float* pe, int pe_rows, hipStream_t st, const float* Pext = nullptr, const In2* in2 = nullptr,
+                        const DropCtl* dc = nullptr) {
     for (int i = 0; i < (int)nd.ops.size(); ++i) {
         const Op& o = nd.ops[i];
         const int out = i + 1;
@@ -325,12 +352,14 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
             g.Radd = o.res >= 0 ? (o.res == 0 ? X : c.Y[o.res]) : nullptr;
             g.gA = gin; g.gB = gP; g.gC = c.gY[out]; g.gBias = gP; g.gZ = c.gY[out];
             g.gR = o.res >= 0 ? (o.res == 0 ? gX : c.gY[o.res]) : 0;
+            g.drop = drop_args(dc, i, o.drop);
             launch_gemm(true, true, g, G, st);
         } else if (o.type == OP_LN) {
             LnArgs a{};
             a.X = in; a.Y = c.Y[out]; a.gamma = P + o.w; a.beta = P + o.b;
             a.mean = save ? c.mean[out] : nullptr; a.rstd = save ? c.rstd[out] : nullptr;
             a.M = M; a.N = o.out_dim; a.gX = gin; a.gY = c.gY[out]; a.gP = gP; a.gS = M;
+            a.drop = drop_args(dc, i, o.drop);
             dim3 grid((M + 3) / 4, G), block(256);
             if (o.out_dim == 256) hipLaunchKernelGGL((layernorm_fwd_kernel<4>), grid, block, 0, st, a);
             else if (o.out_dim == 512) hipLaunchKernelGGL((layernorm_fwd_kernel<8>), grid, block, 0, st, a);
@@ -363,7 +392,7 @@ __global__ void head_bwd_dx_act_kernel(HeadBwdArgs a, const float* Zp, long gZ, 
 // backward of one net.  c.dY[last] must hold the gradient w.r.t. the head output.  Gr == nullptr: data
 // gradients only (the critics inside the actor step).  Returns the input gradient in c.dY[0] when wanted.
 static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, long gG, const float* X, long gX, int M, int G,
-                         Ctx& c, bool want_input_grad, hipStream_t st, const In2* in2 = nullptr) {
+                         Ctx& c, bool want_input_grad, hipStream_t st, const In2* in2 = nullptr, const DropCtl* dc = nullptr) {
     for (int i = (int)nd.ops.size() - 1; i >= 0; --i) {
         const Op& o = nd.ops[i];
         const int out = i + 1;
@@ -401,13 +430,18 @@ static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, l
             a.colsum = prod_bias_grad;
             a.M = M; a.N = o.out_dim;
             a.gA = c.gY[out]; a.gP = Gr ? gG : gP; a.gS = M;
+            a.dmask = drop_args(dc, i, o.drop);  // this norm's output was dropped: mask the incoming gradient
+            if (dc && prod_lin && po->drop && po->res >= 0) {  // producer = Linear -> dropout -> + residual: its dZ is the masked dX
+                a.dXm = c.dYm[o.src];
+                a.omask = drop_args(dc, prod, po->drop);
+            }
             // gamma is read with the PARAMETER stride, dgamma written with the GRADIENT stride: both nets use the
             // same block layout, so the strides coincide whenever Gr != nullptr (gG == gP is asserted at create)
             dim3 grid((M + 7) / 8, G), block(256);
             if (o.out_dim == 256) hipLaunchKernelGGL((layernorm_bwd_kernel<4>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((layernorm_bwd_kernel<8>), grid, block, 0, st, a);
         } else {  // LINEAR: c.dY[out] already holds dZ (act' and bias column sums were fused by its writer)
-            const float* dZ = c.dY[out];
+            const float* dZ = (dc && o.drop && o.res >= 0) ? c.dYm[out] : c.dY[out];
             if (thin_ok(o) && o.src == 0 && g_force_variant == 0) {
                 ThinArgs a = thin_input(o, X, gX, in2, M);
                 a.dZ = dZ; a.gY = c.gY[out];
@@ -440,6 +474,7 @@ static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, l
                 if (rc >= 0 && rc != i) { g.Radd = c.dY[rc + 1]; g.gR = c.gY[rc + 1]; }
                 if (prod_act) { g.dactZ = c.Z[o.src]; g.dact = po->act; g.gDZ = c.gY[o.src]; }
                 if (prod_bias_grad) { g.colsum = prod_bias_grad; g.gCol = gG; }
+                if (dc && prod_lin && po->drop && po->res < 0) g.dmask = drop_args(dc, prod, po->drop);  // producer's own dropout
                 if (Gr) launch_gemm_bwd_pair(gw, g, G, st);
                 else launch_gemm(true, false, g, G, st);
             }
@@ -641,7 +676,7 @@ struct tvc_sac {
 static long ctx_bytes(const NetDef& nd, int M, int G, bool train) {
     long f = 0;
     for (size_t b = 1; b < nd.buf_dim.size(); ++b) {
-        f += (long)G * M * nd.buf_dim[b] * (train ? 3 : 0);  // Y, dY, Z
+        f += (long)G * M * nd.buf_dim[b] * (train ? 4 : 0);  // Y, dY, Z (+ dYm where a dropped Linear feeds a residual)
         f += train ? 2L * G * M : 0;                         // mean, rstd
     }
     f += (long)G * M * nd.buf_dim[0];  // dY[0]
@@ -655,13 +690,15 @@ static char* carve(char*& p, long bytes) {
 static void ctx_alloc_train(Ctx& c, const NetDef& nd, int M, int G, char*& p) {
     const size_t nb = nd.buf_dim.size();
     c.M = M; c.G = G;
-    c.Y.assign(nb, nullptr); c.dY.assign(nb, nullptr); c.Z.assign(nb, nullptr);
+    c.Y.assign(nb, nullptr); c.dY.assign(nb, nullptr); c.Z.assign(nb, nullptr); c.dYm.assign(nb, nullptr);
     c.mean.assign(nb, nullptr); c.rstd.assign(nb, nullptr); c.gY.assign(nb, 0);
     for (size_t b = 0; b < nb; ++b) {
         const long n = (long)M * nd.buf_dim[b];
         c.gY[b] = n;
         c.dY[b] = (float*)carve(p, n * G * 4);
         if (b == 0) continue;
+        const Op& po = nd.ops[b - 1];
+        if (po.type == OP_LINEAR && po.drop && po.res >= 0) c.dYm[b] = (float*)carve(p, n * G * 4);
         c.Y[b] = (float*)carve(p, n * G * 4);
         c.Z[b] = (float*)carve(p, n * G * 4);
         c.mean[b] = (float*)carve(p, (long)M * G * 4);
@@ -704,6 +741,7 @@ void tvc_sac_default_cfg(tvc_sac_cfg* c, int32_t family) {
     c->mlp1 = 256; c->mlp2 = 256;
     c->critic1 = family == 0 ? 512 : 256; c->critic2 = 256;                              // agent/...:593-603
     c->batch_size = 256; c->max_act_rows = 65536; c->pe_rows = 1;
+    c->dropout_p = 0.0f; c->nhead = 8;
     c->gamma = 0.99f; c->alpha = 0.2f; c->tau = 0.005f; c->lr = 3e-4f;                   // agent/...:971,998,1005,623
     c->adam_b1 = 0.9f; c->adam_b2 = 0.999f; c->adam_eps = 1e-8f;
 }
@@ -866,6 +904,16 @@ static const float* critic_input(tvc_sac* h, const float* s, const float* a, In2
     return h->xcat;
 }
 
+// dropout control of one forward call of an update: site bases 0 (actor), 100 + 20 * call (critics: call 1 = targets,
+// 2 = online nets in the critic loss, 3 = online nets in the policy loss); the counter is the actor's Adam step count,
+// constant during an update and advanced by its last kernel
+static const DropCtl* drop_ctl(tvc_sac* h, DropCtl& dc, unsigned site_base) {
+    if (!(h->cfg.dropout_p > 0.0f)) return nullptr;
+    const unsigned thresh = (unsigned)lroundf(h->cfg.dropout_p * 65536.0f);
+    dc.ctr = &h->clk[1].step; dc.thresh = thresh; dc.scale = 65536.0f / (float)(65536u - thresh); dc.site_base = site_base;
+    return &dc;
+}
+
 static int check_batch_ptrs(const void* a, const void* b, const void* c) {
     if (!a || !b || !c) return tvc::set_error(TVC_EINVAL, "null batch pointer");
     return 0;
@@ -886,23 +934,28 @@ int tvc_sac_critic_grads(tvc_sac* h, const float* s, const float* a, const float
     // backward -- now, and the positional-encoding table is indexed modulo its rows
     hipLaunchKernelGGL(update_prep_kernel, dim3(1 + (2 * B * no + 255) / 256), dim3(256), 0, st, s, a, s2, losses, h->xs2, B, no, A,
                        0.1f);
-    net_forward(h->actor, h->P_actor(), 0, h->xs2, 0, 2 * B, 1, h->actx, true, pe, c.pe_rows, st);
+    DropCtl dca, dcq;
+    net_forward(h->actor, h->P_actor(), 0, h->xs2, 0, 2 * B, 1, h->actx, true, pe, c.pe_rows, st, nullptr, nullptr,
+                drop_ctl(h, dca, 0));
     h->actor_fwd_valid = true;
     // target: a' ~ pi(s'), y = r + gamma (1-d) min(tq1, tq2)(s', a')
     hipLaunchKernelGGL(sample_action_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, h->actx.Y.back() + (long)B * 2 * A,
                        eps_next, h->a_tmp, (float*)nullptr, (float*)nullptr, B, A, 0);
     In2 in2;
     const float* x = critic_input(h, s2, h->a_tmp, in2, st);
-    net_forward(h->critic, h->P_tq(), h->n_critic, x, 0, B, 2, h->cctx, false, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr);
+    net_forward(h->critic, h->P_tq(), h->n_critic, x, 0, B, 2, h->cctx, false, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr,
+                drop_ctl(h, dcq, 120));
     hipLaunchKernelGGL(td_target_kernel, dim3((B + 255) / 256), dim3(256), 0, st, h->cctx.Y.back(), r, d, h->y, B, c.gamma);
     // online critics on (s, a): forward (saved), loss, backward
     x = critic_input(h, s, a, in2, st);
-    net_forward(h->critic, h->P_q(), h->n_critic, x, 0, B, 2, h->cctx, true, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr);
+    net_forward(h->critic, h->P_q(), h->n_critic, x, 0, B, 2, h->cctx, true, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr,
+                drop_ctl(h, dcq, 140));
     hipLaunchKernelGGL(q_loss_kernel, dim3((B + 255) / 256, 2), dim3(256), 0, st, h->cctx.Y.back(), h->y, h->cctx.dY.back(),
                        losses, B);
     if (!h->grads_clean[0]) TVC_HIP_CHECK(hipMemsetAsync(h->G_q(), 0, 2 * h->n_critic * sizeof(float), st));
     h->grads_clean[0] = false;
-    net_backward(h->critic, h->P_q(), h->n_critic, h->G_q(), h->n_critic, x, 0, B, 2, h->cctx, false, st, in2.X2 ? &in2 : nullptr);
+    net_backward(h->critic, h->P_q(), h->n_critic, h->G_q(), h->n_critic, x, 0, B, 2, h->cctx, false, st, in2.X2 ? &in2 : nullptr,
+                 drop_ctl(h, dcq, 140));
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -933,27 +986,30 @@ int tvc_sac_actor_grads(tvc_sac* h, const float* s, const float* eps_new, float*
     const int B = c.batch_size, A = c.act_dim, no = c.obs_dim, nin = no + A;
     const float* pe = c.family == 0 ? h->pe : nullptr;
     const float* xin = s;
+    DropCtl dca, dcq;
     if (h->actor_fwd_valid) {  // rows [0, B) of the stacked forward made by tvc_sac_critic_grads of this update
         xin = h->xs2;
         h->actor_fwd_valid = false;
     } else {
-        net_forward(h->actor, h->P_actor(), 0, s, 0, B, 1, h->actx, true, pe, c.pe_rows, st);
+        net_forward(h->actor, h->P_actor(), 0, s, 0, B, 1, h->actx, true, pe, c.pe_rows, st, nullptr, nullptr, drop_ctl(h, dca, 0));
     }
     const float* head = h->actx.Y.back();
     hipLaunchKernelGGL(sample_action_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, head, eps_new, h->a_tmp, h->mean_tmp,
                        h->ls_tmp, B, A, 0);
     In2 in2;
     const float* x = critic_input(h, s, h->a_tmp, in2, st);
-    net_forward(h->critic, h->P_q(), h->n_critic, x, 0, B, 2, h->cctx, true, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr);
+    net_forward(h->critic, h->P_q(), h->n_critic, x, 0, B, 2, h->cctx, true, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr,
+                drop_ctl(h, dcq, 160));
     hipLaunchKernelGGL(actor_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, st, h->cctx.Y.back(), h->ls_tmp, eps_new,
                        h->cctx.dY.back(), losses, B, A, c.alpha);
     // data gradients only through the critics (the reference also fills q.grad here, then discards it)
-    net_backward(h->critic, h->P_q(), h->n_critic, nullptr, 0, x, 0, B, 2, h->cctx, true, st, in2.X2 ? &in2 : nullptr);
+    net_backward(h->critic, h->P_q(), h->n_critic, nullptr, 0, x, 0, B, 2, h->cctx, true, st, in2.X2 ? &in2 : nullptr,
+                 drop_ctl(h, dcq, 160));
     hipLaunchKernelGGL(actor_head_grad_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, h->cctx.dY[0], h->cctx.gY[0], nin, no,
                        head, eps_new, h->actx.dY.back(), B, A, c.alpha);
     if (!h->grads_clean[1]) TVC_HIP_CHECK(hipMemsetAsync(h->G_actor(), 0, h->n_actor * sizeof(float), st));
     h->grads_clean[1] = false;
-    net_backward(h->actor, h->P_actor(), 0, h->G_actor(), 0, xin, 0, B, 1, h->actx, false, st);
+    net_backward(h->actor, h->P_actor(), 0, h->G_actor(), 0, xin, 0, B, 1, h->actx, false, st, nullptr, drop_ctl(h, dca, 0));
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -19,13 +19,16 @@ class VecTrainer:
     def __init__(self, num_envs: int, device="cuda:0", config: Optional[dict] = None, family: int = 0, batch_size: int = 256,
                  replay_capacity: int = 1_000_000, seed: int = 42, rank: int = 0, world: int = 1, updates_per_step: int = 1,
                  max_episode_steps: int = 1000, enable_curiosity: bool = False, overlap: bool = True,
-                 enable_hierarchical: bool = False, enable_safety: bool = False, **env_over):
+                 enable_hierarchical: bool = False, enable_safety: bool = False, dropout_p: Optional[float] = None, **env_over):
         self.device = torch.device(device)
         self.n, self.B, self.world, self.rank = num_envs, batch_size, world, rank
         self.updates_per_step = updates_per_step
         self.env = VecRocketTVCEnv(num_envs, device=self.device, config=config, max_episode_steps=max_episode_steps,
                                    seed=seed, env_id_offset=rank * num_envs, want_final_obs=True, **env_over)
-        self.sac = NativeSAC(sac_cfg(family, batch_size=batch_size, max_act_rows=num_envs), device=self.device, seed=seed)
+        # the reference's update runs in train mode (Dropout(0.1) active in the policy and the critics); family 1 has none
+        self.dropout_p = (0.1 if family == 0 else 0.0) if dropout_p is None else float(dropout_p)
+        self.sac = NativeSAC(sac_cfg(family, batch_size=batch_size, max_act_rows=num_envs, dropout_p=self.dropout_p),
+                             device=self.device, seed=seed)
         broadcast_parameters(self.sac.params)  # identical replicas (rank 0's initialisation)
         self.sac.sync_derived()
         self.rb = ReplayBuffer(replay_capacity, 10, 2, device=self.device, seed=seed * 1000003 + rank)
@@ -211,6 +214,7 @@ def bench_train(args, world, rank, device):
     return {"step_fn": lambda k: tr.step(True), "env": tr.env, "trainer": tr,
             "extra": {"updates_per_step": float(utd), "sac": {"family": fam, "batch": 256, "replay_capacity": 1_000_000,
                                                       "utd": f"{utd} update(s) per vector step", "dtype": "f32 MFMA",
+                                                      "dropout_in_update": tr.dropout_p,
                                                       "acting": "hierarchical goal policy + safety layer + curiosity bonus (shipped config.yaml)"
                                                       if shipped else "SAC policy",
                                                       "domain_randomisation": "off (shipped env)" if stage is None
