@@ -160,6 +160,34 @@ def test_act_large_ragged_batch_and_sampling():
     sac.close()
 
 
+@pytest.mark.parametrize("n", [65536, 65536 - 37, 6144 + 5])
+def test_act_at_full_chip_row_counts(n):
+    """the acting kernels that only run at large row counts: 128x128-per-wave tiles (one workgroup per CU, n >= ~56k) and the
+    32-row fused Linear+LayerNorm kernel (n >= 6144), checked on a sample of rows against the restatement (PE(0): rows are
+    independent), ragged last tile included"""
+    from tvc_ai_amd.agent import NativeSAC, sac_cfg
+    torch.set_num_threads(8)
+    sac = NativeSAC(sac_cfg(0, batch_size=64, max_act_rows=65536), seed=13)
+    for name, _, rows, cols in sac.table:  # non-trivial norms / biases so that every epilogue term is exercised
+        if name.startswith("policy.") and cols == 1:
+            sac.view(name).add_(0.1 * torch.randn(rows, device="cuda", generator=torch.Generator(device="cuda").manual_seed(rows)))
+    sac.sync_derived()
+    P = sac.export_reference_state("policy")
+    g = torch.Generator().manual_seed(n)
+    obs = torch.randn(n, 10, generator=g) * 0.5
+    eps = torch.randn(n, 2, generator=g)
+    act, mean, ls = sac.act(*cuda(obs), cuda(eps)[0])
+    pick = torch.cat([torch.arange(0, 300), torch.randint(0, n, (1200,), generator=g), torch.arange(n - 300, n)])
+    with torch.no_grad():
+        m_ref, ls_ref = st.actor_forward(P, obs[pick], batch_pe=False)
+    np.testing.assert_allclose(mean.cpu()[pick].numpy(), m_ref.numpy(), atol=3e-4, rtol=0)
+    np.testing.assert_allclose(ls.cpu()[pick].numpy(), ls_ref.numpy(), atol=3e-4, rtol=0)
+    a_ref = (m_ref + torch.exp(ls_ref) * eps[pick]).clamp(-1, 1)
+    np.testing.assert_allclose(act.cpu()[pick].numpy(), a_ref.numpy(), atol=1e-3, rtol=0)
+    assert torch.isfinite(mean).all() and torch.isfinite(ls).all()
+    sac.close()
+
+
 def test_replay_buffer_roundtrip_and_uniformity():
     from tvc_ai_amd.agent import ReplayBuffer
     rb = ReplayBuffer(1000, 10, 2, seed=7)

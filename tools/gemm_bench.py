@@ -29,4 +29,37 @@ for (M, N, K) in shapes:
             e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / reps * 1e3)
         line += f" v{v}: {best:7.1f} us {2*M*N*K/best/1e6:6.1f} TF err {err:.1e} |"
+    if M > 1024 and N in (256, 512):  # fused Linear (+GELU for N = 512) + residual + LayerNorm (tvc_nn_linear_ln_forward)
+        R = torch.randn(M, N, device="cuda"); gam = torch.ones(N, device="cuda"); bet = torch.zeros(N, device="cuda")
+        act = 0 if N == 256 else 1
+        g = torch.cuda.CUDAGraph(); s_ = torch.cuda.Stream(); s_.wait_stream(torch.cuda.current_stream())
+        call = lambda: L.tvc_nn_linear_ln_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), gam.data_ptr(), bet.data_ptr(),
+                                                  Y.data_ptr(), M, N, K, act, st())
+        with torch.cuda.stream(s_):
+            call()
+            with torch.cuda.graph(g, stream=s_):
+                for _ in range(20):
+                    call()
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 20 * 1e3)
+        line += f" +res+LN: {best:7.1f} us {2*M*N*K/best/1e6:6.1f} TF |"
+    if M > 1024:  # the vendor library on the same shape (torch.nn.functional.linear -> hipBLASLt / rocBLAS), bias included
+        g = torch.cuda.CUDAGraph(); s_ = torch.cuda.Stream(); s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            for _ in range(3):
+                torch.nn.functional.linear(X, W, b, ) if False else torch.addmm(b, X, W.t(), out=Y)
+            with torch.cuda.graph(g, stream=s_):
+                for _ in range(20):
+                    torch.addmm(b, X, W.t(), out=Y)
+        torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 20 * 1e3)
+        line += f" torch.addmm: {best:7.1f} us {2*M*N*K/best/1e6:6.1f} TF |"
     print(line, flush=True)

@@ -16,9 +16,29 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };  // sigmoid: forward only (SE gate)
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
+// erf as one branch-free rational x P(x^2) / Q(x^2) on [-4, 4] (the float kernel of Eigen / XLA): max abs error 4.5e-7,
+// i.e. GELU within 1e-6 of the erff-based one, at ~20 VALU instructions instead of a three-range libm routine whose
+// divergent ranges all execute -- it matters in the epilogues that apply it to 256 values per lane
+__device__ __forceinline__ float fast_erff(float x) {
+    x = fminf(fmaxf(x, -4.0f), 4.0f);
+    const float x2 = x * x;
+    float p = -2.72614225801306e-10f;
+    p = fmaf(p, x2, 2.77068142495902e-08f);
+    p = fmaf(p, x2, -2.10102402082508e-06f);
+    p = fmaf(p, x2, -5.69250639462346e-05f);
+    p = fmaf(p, x2, -7.34990630326855e-04f);
+    p = fmaf(p, x2, -2.95459980854025e-03f);
+    p = fmaf(p, x2, -1.60960333262415e-02f);
+    float q = -1.45660718464996e-05f;
+    q = fmaf(q, x2, -2.13374055278905e-04f);
+    q = fmaf(q, x2, -1.68282697438203e-03f);
+    q = fmaf(q, x2, -7.37332916720468e-03f);
+    q = fmaf(q, x2, -1.42647390514189e-02f);
+    return x * p / q;
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + fast_erff(x * 0.7071067811865476f)); }
 __device__ __forceinline__ float gelu_grad(float x) {
-    return 0.5f * (1.0f + erff(x * 0.7071067811865476f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    return 0.5f * (1.0f + fast_erff(x * 0.7071067811865476f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 __device__ __forceinline__ float act_f(float x, int act) {
     return act == ACT_GELU ? gelu_f(x) : (act == ACT_RELU ? fmaxf(x, 0.0f) : (act == ACT_SIGMOID ? 1.0f / (1.0f + expf(-x)) : x));
