@@ -414,15 +414,15 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
         except Exception as e:
             rep["sac_learner_only"] = {"error": str(e)}
         # the whole acting pass alone (policy forward on all N observations + Gaussian sample): MFMA utilisation of the
-        # 13 GEMMs together.  MACs per row: embed 10*256, 4 x (256*256 folded attention + 256*512 + 512*256), head
-        # 256*512 + 512*512 + 512*4 (family 1: 10*256 + 256*256 + 256*4)
+        # 12 GEMMs together.  MACs per row as executed: 10*256 (embedding folded with layer 0's attention), 3 x 256*256 (folded
+        # attention of layers 1-3), 4 x (256*512 + 512*256), head 256*512 + 512*512 + 512*4 (family 1: 10*256 + 256*256 + 256*4)
         try:
             from tvc_ai_amd.agent import NativeSAC, sac_cfg
             sac = NativeSAC(sac_cfg(args.family, batch_size=256, max_act_rows=n), device=device, seed=2)
             ob, ep = torch.randn(n, 10, device=device), torch.randn(n, 2, device=device)
             outs = tuple(torch.empty(n, 2, device=device) for _ in range(3))
             us_a = graph_time_us(lambda k: sac.act(ob, ep, out=outs), 5, device)
-            macs = (10 * 256 + 4 * (256 * 256 + 2 * 256 * 512) + 256 * 512 + 512 * 512 + 512 * 4) if args.family == 0 \
+            macs = (10 * 256 + 3 * 256 * 256 + 4 * (2 * 256 * 512) + 256 * 512 + 512 * 512 + 512 * 4) if args.family == 0 \
                 else (10 * 256 + 256 * 256 + 256 * 4)
             tf_a = 2.0 * macs * n / (us_a * 1e-6) / 1e12
             rep["acting_pass_only"] = {"us_per_call": us_a, "rows": n, "rows_per_s": n / (us_a * 1e-6), "mfma_tflops": tf_a,

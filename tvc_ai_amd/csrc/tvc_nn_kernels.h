@@ -691,6 +691,73 @@ __global__ void __launch_bounds__(256) thin_fwd_kernel(ThinArgs a) {
         Y[o] = v;
     }
 }
+// thin Linear + LayerNorm over exactly 256 output columns (one thread per column, the norm is a workgroup reduction per
+// row): the acting net's first block once the embedding and the first attention sublayer are folded into one
+// obs -> d_model Linear (tvc_sac.hip: derive_infer)
+__global__ void __launch_bounds__(256) thin_fwd_ln_kernel(ThinArgs a, const float* __restrict__ gamma, const float* __restrict__ beta) {
+    __shared__ float xs[THIN_ROWS][THIN_K];
+    __shared__ float part[2][4][THIN_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row0 = blockIdx.x * THIN_ROWS;
+    if (tid < THIN_ROWS * THIN_K) xs[tid / THIN_K][tid % THIN_K] = thin_x(a, a.X, a.X2, row0 + tid / THIN_K, tid % THIN_K);
+    const float* W = a.W + (long)tid * a.K;
+    float w[THIN_K];
+#pragma unroll
+    for (int k = 0; k < THIN_K; ++k) {
+        const float t = W[min(k, a.K - 1)];
+        w[k] = k < a.K ? t : 0.0f;
+    }
+    const float b = a.bias ? a.bias[tid] : 0.0f;
+    const float gm = gamma[tid], bt = beta[tid];
+    __syncthreads();
+    float v[THIN_ROWS];
+#pragma unroll
+    for (int r = 0; r < THIN_ROWS; ++r) {
+        float t = b;
+#pragma unroll
+        for (int k = 0; k < THIN_K; ++k) t = fmaf(xs[r][k], w[k], t);
+        v[r] = act_f(t, a.act);
+        float s = v[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) part[0][wave][r] = s;
+    }
+    __syncthreads();
+    float mean[THIN_ROWS];
+#pragma unroll
+    for (int r = 0; r < THIN_ROWS; ++r) {
+        mean[r] = (part[0][0][r] + part[0][1][r] + part[0][2][r] + part[0][3][r]) * (1.0f / 256.0f);
+        const float d = v[r] - mean[r];
+        float s = d * d;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) part[1][wave][r] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < THIN_ROWS; ++r) {
+        const float rstd = rsqrtf((part[1][0][r] + part[1][1][r] + part[1][2][r] + part[1][3][r]) * (1.0f / 256.0f) + 1e-5f);
+        const int row = row0 + r;
+        if (row < a.M) a.Y[(long)row * 256 + tid] = (v[r] - mean[r]) * rstd * gm + bt;
+    }
+}
+// W'[o, k] = W_e[o, k] + sum_j W_ov[o, j] W_e[j, k];  b'[o] = be[o] + sum_j W_ov[o, j] be[j] + b_ov[o], be = b_e + pe0:
+// the embedding (+ PE(0)) and the first folded attention sublayer x + W_ov x + b_ov as ONE obs -> d Linear
+__global__ void __launch_bounds__(256) fold_embed_kernel(const float* __restrict__ We, const float* __restrict__ be_,
+                                                         const float* __restrict__ pe0, const float* __restrict__ Wov,
+                                                         const float* __restrict__ bov, float* __restrict__ Wout,
+                                                         float* __restrict__ bout, int d, int obs) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= d * (obs + 1)) return;
+    const int o = idx / (obs + 1), k = idx - o * (obs + 1);
+    float acc = 0.0f;
+    if (k < obs) {
+        for (int j = 0; j < d; ++j) acc = fmaf(Wov[(long)o * d + j], We[(long)j * obs + k], acc);
+        Wout[(long)o * obs + k] = We[(long)o * obs + k] + acc;
+    } else {
+        for (int j = 0; j < d; ++j) acc = fmaf(Wov[(long)o * d + j], be_[j] + (pe0 ? pe0[j] : 0.0f), acc);
+        bout[o] = be_[o] + (pe0 ? pe0[o] : 0.0f) + acc + bov[o];
+    }
+}
 // dW[n, k] = sum_m dZ[m, n] X[m, k]: 32 weight rows per workgroup, the 8 half-waves split the batch rows
 __global__ void __launch_bounds__(256) thin_wgrad_kernel(ThinArgs a) {
     __shared__ float xs[64][THIN_K];

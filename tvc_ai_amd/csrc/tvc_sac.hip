@@ -111,8 +111,13 @@ static NetDef build_actor(const tvc_sac_cfg& c) {
 // Acting-only variant of the actor: at sequence length 1 attention is out_proj(v_proj(x)), two
 // back-to-back Linear layers with nothing in between, so for inference they fold into ONE 256x256 Linear with
 // W_ov = W_o W_v, b_ov = W_o b_v + b_o (re-derived after every actor update; the training net keeps them apart).
-struct FoldInfo { int layers = 0; long v_w = 0, v_b = 0, o_w = 0, o_b = 0, layer_stride = 0; int d = 0; };
-static NetDef derive_infer(const NetDef& a, FoldInfo& fi) {
+// ... and, when every row uses PE(0) (pe_rows == 1) and the observation is at most 16 wide, the embedding folds into
+// the first of them: LN(x0 + W_ov x0 + b_ov) with x0 = W_e obs + b_e + pe0 is LN(W' obs + b'), one thin Linear + LN.
+struct FoldInfo {
+    int layers = 0; long v_w = 0, v_b = 0, o_w = 0, o_b = 0, layer_stride = 0; int d = 0;
+    bool embed = false; long e_w = 0, e_b = 0, e_off = 0; int obs = 0;  // embedding fold: source offsets, offset in the derived buffer
+};
+static NetDef derive_infer(const NetDef& a, FoldInfo& fi, bool fold_embed) {
     NetDef n;
     n.in_dim = a.in_dim;
     std::vector<int> map(a.ops.size() + 1, -1);
@@ -140,6 +145,31 @@ static NetDef derive_infer(const NetDef& a, FoldInfo& fi) {
             c.mul = op.mul >= 0 ? map[op.mul] : -1;
             n.ops.push_back(c);
             map[i + 1] = (int)n.ops.size();
+        }
+    }
+    // ops[0] = embedding (src 0, row table), ops[1] = folded attention of layer 0 reading and adding buffer 1, ops[2] = norm1
+    if (fold_embed && fi.layers > 0 && n.ops.size() >= 3 && n.ops[0].type == OP_LINEAR && n.ops[0].rowtab && n.ops[0].src == 0 &&
+        n.ops[0].in_dim <= THIN_K && n.ops[1].ext == 1 && n.ops[1].src == 1 && n.ops[1].res == 1 && n.ops[2].type == OP_LN &&
+        n.ops[2].src == 2) {
+        bool only = true;  // buffers 1 and 2 must have no other reader
+        for (size_t i = 2; i < n.ops.size(); ++i) {
+            const Op& o = n.ops[i];
+            if (o.src == 1 || o.res == 1 || o.mul == 1 || (i > 2 && (o.src == 2 || o.res == 2 || o.mul == 2))) only = false;
+        }
+        if (only) {
+            fi.embed = true; fi.e_w = n.ops[0].w; fi.e_b = n.ops[0].b; fi.obs = n.ops[0].in_dim;
+            fi.e_off = (((long)fi.layers * ((long)fi.d * fi.d + fi.d)) + 3) & ~3L;
+            Op e = n.ops[0];
+            e.rowtab = 0; e.ext = 1; e.w = fi.e_off; e.b = fi.e_off + (long)fi.d * fi.obs;
+            std::vector<Op> ops;
+            ops.push_back(e);
+            for (size_t i = 2; i < n.ops.size(); ++i) {
+                Op o = n.ops[i];
+                auto shift = [](int b) { return b >= 2 ? b - 1 : b; };
+                o.src = shift(o.src); o.res = o.res >= 0 ? shift(o.res) : -1; o.mul = o.mul >= 0 ? shift(o.mul) : -1;
+                ops.push_back(o);
+            }
+            n.ops = ops;
         }
     }
     n.finish();
@@ -302,11 +332,19 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
         const long gin = o.src == 0 ? gX : c.gY[o.src];
         if (thin_ok(o) && g_force_variant == 0) {  // input layer (in_dim <= 16): plain-FMA kernel, reads [X | X2] in place
             ThinArgs a = thin_input(o, in, gin, in2, M);
-            a.W = P + o.w; a.bias = P + o.b; a.gW = gP; a.gB = gP;
+            a.W = (o.ext ? Pext : P) + o.w; a.bias = (o.ext ? Pext : P) + o.b; a.gW = gP; a.gB = gP;
             if (o.rowtab && pe) { a.rowtab = pe; a.rowtab_rows = pe_rows; }
             if (o.mul >= 0) a.Mul = c.Y[o.mul];
             a.Y = c.Y[out]; a.gY = c.gY[out]; a.act = o.act;
             a.Z = (save && o.act != ACT_NONE) ? c.Z[out] : nullptr;
+            if (!save && G == 1 && o.out_dim == 256 && o.mul < 0 && !(o.rowtab && pe) && i + 1 < (int)nd.ops.size() &&
+                nd.ops[i + 1].type == OP_LN && nd.ops[i + 1].src == out && nd.last_use[out] == i + 1) {
+                const Op& ln = nd.ops[i + 1];  // thin Linear + LayerNorm in one launch (the folded embedding block)
+                a.Y = c.Y[out + 1];
+                hipLaunchKernelGGL(thin_fwd_ln_kernel, dim3((M + THIN_ROWS - 1) / THIN_ROWS), dim3(256), 0, st, a, P + ln.w, P + ln.b);
+                i += 1;
+                continue;
+            }
             hipLaunchKernelGGL(thin_fwd_kernel, dim3((M + THIN_ROWS - 1) / THIN_ROWS, (o.out_dim + 255) / 256, G), dim3(256), 0, st, a);
             continue;
         }
@@ -798,7 +836,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     if (!h) return tvc::set_error(TVC_ENOMEM, "host allocation failed");
     h->cfg = *cfg; h->device = device;
     h->actor = build_actor(*cfg); h->critic = build_critic(*cfg);
-    h->actor_inf = derive_infer(h->actor, h->fold);
+    h->actor_inf = derive_infer(h->actor, h->fold, cfg->pe_rows == 1);
     h->n_actor = h->actor.n_params; h->n_critic = h->critic.n_params;
     h->params = params; h->grads = grads; h->adam_m = adam_m; h->adam_v = adam_v;
     const int B = cfg->batch_size, A = cfg->act_dim, NA = cfg->max_act_rows;
@@ -807,7 +845,8 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     long bytes = ctx_bytes(h->actor, 2 * B, 1, true) + ctx_bytes(h->critic, B, 2, true) + 8L * NA * maxd * 4 + 2L * B * cfg->obs_dim * 4 + 512;
     bytes += (long)cfg->pe_rows * cfg->d_model * 4 + (long)B * (cfg->obs_dim + A) * 4 * 2 + (long)B * 64 + (1 << 16);
     bytes += 256L * (4 * (h->actor.buf_dim.size() + h->critic.buf_dim.size()) * 3 + 64);
-    h->ov_floats = (long)std::max(1, h->fold.layers) * ((long)h->fold.d * h->fold.d + h->fold.d + 4);
+    h->ov_floats = (long)std::max(1, h->fold.layers) * ((long)h->fold.d * h->fold.d + h->fold.d + 4) +
+                   (long)h->fold.d * (h->fold.obs + 1) + 8;
     bytes += 2 * h->ov_floats * 4 + h->n_actor * 4 + 2048;
     hipError_t he = hipMalloc(&h->slab, bytes);
     if (he != hipSuccess) {
@@ -1031,6 +1070,10 @@ static void refresh_folded(tvc_sac* h, hipStream_t st) {
     b.bias = h->P_actor() + f.o_b;
     b.gA = f.layer_stride; b.gB = f.layer_stride; b.gC = ostride; b.gBias = f.layer_stride;
     launch_gemm(true, true, b, f.layers, st);
+    if (f.embed)  // W', b' of the folded embedding, from layer 0's W_ov / b_ov just computed
+        hipLaunchKernelGGL(fold_embed_kernel, dim3((d * (f.obs + 1) + 255) / 256), dim3(256), 0, st, h->P_actor() + f.e_w,
+                           h->P_actor() + f.e_b, h->cfg.family == 0 ? h->pe : nullptr, h->ov, h->ov + (long)d * d, h->ov + f.e_off,
+                           h->ov + f.e_off + (long)d * f.obs, d, f.obs);
 }
 
 // Adam step counters (critics, actor) live on the device so that a captured update keeps counting; these two calls
