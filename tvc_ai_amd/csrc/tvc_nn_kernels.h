@@ -746,16 +746,34 @@ __global__ void __launch_bounds__(256) fold_embed_kernel(const float* __restrict
                                                          const float* __restrict__ pe0, const float* __restrict__ Wov,
                                                          const float* __restrict__ bov, float* __restrict__ Wout,
                                                          float* __restrict__ bout, int d, int obs) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= d * (obs + 1)) return;
-    const int o = idx / (obs + 1), k = idx - o * (obs + 1);
-    float acc = 0.0f;
-    if (k < obs) {
-        for (int j = 0; j < d; ++j) acc = fmaf(Wov[(long)o * d + j], We[(long)j * obs + k], acc);
-        Wout[(long)o * obs + k] = We[(long)o * obs + k] + acc;
-    } else {
-        for (int j = 0; j < d; ++j) acc = fmaf(Wov[(long)o * d + j], be_[j] + (pe0 ? pe0[j] : 0.0f), acc);
-        bout[o] = be_[o] + (pe0 ? pe0[o] : 0.0f) + acc + bov[o];
+    // one workgroup per output row o; thread j carries W_ov[o, j] times row j of [W_e | be] (obs + 1 <= 17 values), then a
+    // workgroup reduction per value
+    __shared__ float part[4][THIN_K + 1];
+    const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float acc[THIN_K + 1];
+#pragma unroll
+    for (int k = 0; k <= THIN_K; ++k) acc[k] = 0.0f;
+    for (int j = tid; j < d; j += 256) {
+        const float w = Wov[(long)o * d + j];
+#pragma unroll
+        for (int k = 0; k < THIN_K; ++k) {
+            const float e = We[(long)j * obs + min(k, obs - 1)];
+            acc[k] = fmaf(w, k < obs ? e : 0.0f, acc[k]);
+        }
+        acc[THIN_K] = fmaf(w, be_[j] + (pe0 ? pe0[j] : 0.0f), acc[THIN_K]);
+    }
+#pragma unroll
+    for (int k = 0; k <= THIN_K; ++k) {
+        float v = acc[k];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
+        if (lane == 0) part[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid <= THIN_K) {
+        const float v = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+        if (tid < obs) Wout[(long)o * obs + tid] = We[(long)o * obs + tid] + v;
+        if (tid == THIN_K) bout[o] = be_[o] + (pe0 ? pe0[o] : 0.0f) + v + bov[o];
     }
 }
 // dW[n, k] = sum_m dZ[m, n] X[m, k]: 32 weight rows per workgroup, the 8 half-waves split the batch rows

@@ -1071,7 +1071,7 @@ static void refresh_folded(tvc_sac* h, hipStream_t st) {
     b.gA = f.layer_stride; b.gB = f.layer_stride; b.gC = ostride; b.gBias = f.layer_stride;
     launch_gemm(true, true, b, f.layers, st);
     if (f.embed)  // W', b' of the folded embedding, from layer 0's W_ov / b_ov just computed
-        hipLaunchKernelGGL(fold_embed_kernel, dim3((d * (f.obs + 1) + 255) / 256), dim3(256), 0, st, h->P_actor() + f.e_w,
+        hipLaunchKernelGGL(fold_embed_kernel, dim3(d), dim3(256), 0, st, h->P_actor() + f.e_w,
                            h->P_actor() + f.e_b, h->cfg.family == 0 ? h->pe : nullptr, h->ov, h->ov + (long)d * d, h->ov + f.e_off,
                            h->ov + f.e_off + (long)d * f.obs, d, f.obs);
 }
