@@ -226,7 +226,7 @@ def main():
 
     graph = None
     # physics: one kernel per step -> capture the K launches in one hipGraph (removes the per-launch host cost).
-    # train: ~200 launches per step; eager keeps the graph size independent of K (a 1000-step graph would hold 200k
+    # train: ~140 launches per step; eager keeps the graph size independent of K (a 1000-step graph would hold 140k
     # nodes) and measures the same as a captured loop because the host stays ahead of the device
     use_graph = (not args.no_graph) and (workload == "physics" or (args.graph and world == 1))
     # multi-GPU train: the two gradient all-reduces (RCCL) sit between kernel phases; they are issued eagerly

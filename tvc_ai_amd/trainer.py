@@ -2,8 +2,11 @@
 StateOfTheArtTrainer.run_episode (scripts/train.py:535-620) for N envs per GPU.
 
 One ``step()`` = policy act on N observations -> vector env step -> replay insert (true next observation,
-done = terminated|truncated) -> [uniform sample of B rows -> one SAC update].  Everything is enqueued on the
-current HIP stream with no host synchronisation, so K steps can be captured in one hipGraph.
+done = terminated|truncated) -> [uniform sample of B rows -> SAC update] x updates_per_step.  Everything is enqueued
+without host synchronisation (the update on a second HIP stream beside the acting pass), so K steps can also be
+captured in one hipGraph.  Options mirror the reference's training env / agent switches: curiosity bonus, the
+hierarchical acting path, the safety layer, train-mode dropout in the update; ``save_checkpoint`` / ``load_checkpoint``
+resume a run exactly.
 """
 import time
 from typing import Optional
