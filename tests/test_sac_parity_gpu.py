@@ -141,6 +141,23 @@ def test_mlp_family_updates():
     sac.close()
 
 
+@pytest.mark.parametrize("n", [700, 6144 + 77])
+def test_mlp_family_acting(n):
+    """acting pass of the MLP family below and above the row count where the hidden layer and the head share one launch"""
+    from tvc_ai_amd.agent import NativeSAC, sac_cfg
+    sac = NativeSAC(sac_cfg(1, batch_size=64, max_act_rows=8192), seed=17)
+    P = {k[len("policy."):]: sac.view(k).cpu().clone() for k, *_ in sac.table if k.startswith("policy.")}
+    obs = torch.randn(n, 10) * 0.5
+    eps = torch.randn(n, 2)
+    act, mean, ls = sac.act(*cuda(obs), cuda(eps)[0])
+    with torch.no_grad():
+        m_ref, ls_ref = st.mlp_actor_forward(P, obs)
+    np.testing.assert_allclose(mean.cpu().numpy(), m_ref.numpy(), atol=1e-4, rtol=0)
+    np.testing.assert_allclose(ls.cpu().numpy(), ls_ref.numpy(), atol=1e-4, rtol=0)
+    np.testing.assert_allclose(act.cpu().numpy(), (m_ref + torch.exp(ls_ref) * eps).clamp(-1, 1).numpy(), atol=5e-4, rtol=0)
+    sac.close()
+
+
 def test_act_large_ragged_batch_and_sampling():
     from tvc_ai_amd.agent import NativeSAC, sac_cfg
     n = 5000 + 37

@@ -97,6 +97,7 @@ struct GemmArgs {
 };
 
 constexpr int GBM = 64, GBN = 64, GBK = 16, GLD = GBK + 4;  // LDS rows padded to 20 floats (16-B aligned)
+constexpr int THIN_K = 16, THIN_ROWS = 8;  // widest input handled by the plain-FMA input-layer kernels; rows per workgroup
 
 template <bool KC>
 __device__ __forceinline__ void gemm_load_tile(const float* __restrict__ P, const float* __restrict__ P2, int K1, long ld,
@@ -345,6 +346,9 @@ struct RowLnArgs {
     // optional output head behind the norm (Linear(N -> headN <= 4), the policy's mean / log_std layer): when set, the
     // normalised rows are NOT stored; only headOut[M, headN] = rows . headW^T + headB is
     const float* headW; const float* headB; float* headOut; int headN;
+    // optional generated A operand (GEN instantiations): A[m, k] = genAct(genB[k] + sum_j genX[m, j] genW[k, j]), the thin
+    // input layer (genK <= 16 inputs) evaluated while the k-tiles are staged, so its activation never exists in HBM
+    const float* genX; const float* genW; const float* genB; int genK, genAct, genLd;
 };
 
 template <int JT>  // 16-column MFMA tiles per wave; N = 4 waves * JT * 16  (JT = 4 -> 256, JT = 8 -> 512)
@@ -391,24 +395,60 @@ __device__ __forceinline__ void rowln_normalize(f32x4 (&u)[2][JT], float* red, c
     }
 }
 
-template <int JT, int KS>  // KS: k-tiles (K / 16) when known at compile time (the reference shapes: 16 or 32), 0 = runtime
+constexpr int GEN_LD = THIN_K + 4;  // LDS row of the generated operand's layer: genK weights, the bias, zero padding (16-byte rows)
+__device__ __forceinline__ f32x4 rowln_gen_a(const float (&xr)[GEN_LD], const float* gw, int act, int k0) {
+    // four consecutive k of the generated operand for this thread's row; xr[genK] = 1 picks up the bias slot
+    f32x4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x4* w = reinterpret_cast<const f32x4*>(gw + (long)(k0 + c) * GEN_LD);
+        float v = 0.0f;
+#pragma unroll
+        for (int q = 0; q < GEN_LD / 4; ++q) {
+            const f32x4 w4 = w[q];
+            v = fmaf(xr[4 * q], w4[0], v); v = fmaf(xr[4 * q + 1], w4[1], v);
+            v = fmaf(xr[4 * q + 2], w4[2], v); v = fmaf(xr[4 * q + 3], w4[3], v);
+        }
+        r[c] = act_f(v, act);
+    }
+    return r;
+}
+template <int JT, int KS, bool GEN = false>  // KS: k-tiles (K / 16) when known at compile time (16 or 32), 0 = runtime
 __global__ void __launch_bounds__(256) gemm_rowln_kernel(RowLnArgs g) {
     constexpr int N = 64 * JT;  // 4 waves x JT tiles x 16 columns
     __shared__ __attribute__((aligned(16))) float As[32][GLD];
     __shared__ __attribute__((aligned(16))) float Bs[N][GLD];
     __shared__ float red[128];
+    __shared__ __attribute__((aligned(16))) float gw[GEN ? 256 * GEN_LD : 4];  // generated operand (K <= 256): [K][GEN_LD] rows
     typedef const f32x4* cv4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * 32;
     const int lr = tid >> 2, lk = (tid & 3) * 4;  // loader: row lr (+64p for B), k offset lk
-    const float* ap = g.A + (long)min(m0 + (lr & 31), g.M - 1) * g.lda + lk;
+    const float* ap = GEN ? nullptr : g.A + (long)min(m0 + (lr & 31), g.M - 1) * g.lda + lk;
     const float* bp = g.B + (long)lr * g.ldb + lk;
+    float xr[GEN_LD];
+    if (GEN) {
+        for (int e = tid; e < g.K * GEN_LD; e += 256) {
+            const int k = e / GEN_LD, j = e - k * GEN_LD;
+            gw[e] = j < g.genK ? g.genW[(long)k * g.genK + j] : (j == g.genK ? g.genB[k] : 0.0f);
+        }
+        const float* xp = g.genX + (long)min(m0 + (lr & 31), g.M - 1) * g.genLd;
+#pragma unroll
+        for (int j = 0; j < GEN_LD; ++j) {
+            const float t = xp[min(j, g.genK - 1)];
+            xr[j] = j < g.genK ? t : (j == g.genK ? 1.0f : 0.0f);
+        }
+        __syncthreads();
+    }
     f32x4 acc[2][JT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < JT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 ra = *(cv4)ap, rb[JT];
+    f32x4 ra, rb[JT];
+    ra = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (GEN) { if (tid < 128) ra = rowln_gen_a(xr, gw, g.genAct, lk); }  // waves 0-1 stage the A tile
+    else ra = *(cv4)ap;
 #pragma unroll
     for (int p = 0; p < JT; ++p) rb[p] = *(cv4)(bp + (long)(64 * p) * g.ldb);
     const int nk = KS > 0 ? KS : g.K / GBK;
@@ -421,7 +461,8 @@ __global__ void __launch_bounds__(256) gemm_rowln_kernel(RowLnArgs g) {
         __syncthreads();
         if (kt + 1 < nk) {
             const int ko = (kt + 1) * GBK;
-            ra = *(cv4)(ap + ko);
+            if (GEN) { if (tid < 128) ra = rowln_gen_a(xr, gw, g.genAct, ko + lk); }
+            else ra = *(cv4)(ap + ko);
 #pragma unroll
             for (int p = 0; p < JT; ++p) rb[p] = *(cv4)(bp + (long)(64 * p) * g.ldb + ko);
         }
@@ -452,7 +493,7 @@ __global__ void __launch_bounds__(256) gemm_rowln_kernel(RowLnArgs g) {
                 acc[i][j][r] = v;
             }
     }
-    rowln_normalize<JT>(acc, red, g.gamma, g.beta, wave, lane, N);
+    if (g.gamma) rowln_normalize<JT>(acc, red, g.gamma, g.beta, wave, lane, N);  // no norm: Linear (+act) + output head only
     if (g.gamma2) rowln_normalize<JT>(acc, red, g.gamma2, g.beta2, wave, lane, N);
     if (g.headW) {  // dot every complete row with the head's weight rows: per-wave partials meet through LDS
         __shared__ float hred[4][32][4];
@@ -647,7 +688,6 @@ struct ThinArgs {
     int M, N, K, K1, act;
     long gX, gX2, gW, gB, gY, gDW, gDX;  // group strides (blockIdx.z)
 };
-constexpr int THIN_K = 16, THIN_ROWS = 8;
 __device__ __forceinline__ float thin_x(const ThinArgs& a, const float* X, const float* X2, int row, int k) {
     // clamped address, zero-selected after the load (never a branch around a load)
     const int kc = min(k, a.K - 1), rc = min(row, a.M - 1);

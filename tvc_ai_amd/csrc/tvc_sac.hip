@@ -268,6 +268,11 @@ static void launch_gemm(bool a_kc, bool b_kc, const GemmArgs& g, int G, hipStrea
 static void launch_rowln(const RowLnArgs& a, hipStream_t st) {
     const dim3 grid((a.M + 31) / 32), block(256);
     const int ks = a.K / GBK;
+    if (a.genX) {  // generated A operand (thin input layer folded in): K = the hidden width, at most 256
+        if (a.N == 256) hipLaunchKernelGGL((gemm_rowln_kernel<4, 0, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((gemm_rowln_kernel<8, 0, true>), grid, block, 0, st, a);
+        return;
+    }
 #define TVC_ROWLN(JT)                                                                               \
     do {                                                                                            \
         if (ks == 16) hipLaunchKernelGGL((gemm_rowln_kernel<JT, 16>), grid, block, 0, st, a);       \
@@ -337,6 +342,25 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
             if (o.mul >= 0) a.Mul = c.Y[o.mul];
             a.Y = c.Y[out]; a.gY = c.gY[out]; a.act = o.act;
             a.Z = (save && o.act != ACT_NONE) ? c.Z[out] : nullptr;
+            // MLP family acting: input layer -> hidden Linear (+act) -> output head as ONE launch; the input layer is
+            // evaluated inside the hidden layer's k-loop
+            if (!save && G == 1 && M >= fuse_ln_min_rows() && o.src == 0 && !in2 && !o.rowtab && o.mul < 0 && o.out_dim <= 256 &&
+                (o.out_dim % GBK) == 0 && i + 2 < (int)nd.ops.size() && nd.last_use[out] == i + 1) {
+                const Op& h = nd.ops[i + 1];
+                const Op& ho = nd.ops[i + 2];
+                if (h.type == OP_LINEAR && h.src == out && h.res < 0 && !h.rowtab && !h.ext && (h.out_dim == 256 || h.out_dim == 512) &&
+                    ho.type == OP_HEAD && ho.src == out + 1 && nd.last_use[out + 1] == i + 2 && ho.out_dim <= 4) {
+                    RowLnArgs r{};
+                    r.B = P + h.w; r.M = M; r.N = h.out_dim; r.K = h.in_dim; r.ldb = h.in_dim; r.ldc = h.out_dim;
+                    r.bias = P + h.b; r.act = h.act;
+                    r.headW = P + ho.w; r.headB = P + ho.b; r.headOut = c.Y[out + 2]; r.headN = ho.out_dim;
+                    r.genX = X; r.genW = (o.ext ? Pext : P) + o.w; r.genB = (o.ext ? Pext : P) + o.b; r.genK = o.in_dim;
+                    r.genAct = o.act; r.genLd = o.in_dim;
+                    launch_rowln(r, st);
+                    i += 2;
+                    continue;
+                }
+            }
             if (!save && G == 1 && o.out_dim == 256 && o.mul < 0 && !(o.rowtab && pe) && i + 1 < (int)nd.ops.size() &&
                 nd.ops[i + 1].type == OP_LN && nd.ops[i + 1].src == out && nd.last_use[out] == i + 1) {
                 const Op& ln = nd.ops[i + 1];  // thin Linear + LayerNorm in one launch (the folded embedding block)
@@ -376,6 +400,21 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
             }
             launch_rowln(a, st);
             i += (two ? 2 : 1) + (head ? 1 : 0);
+            continue;
+        }
+        // acting pass of the MLP family: hidden Linear (+ReLU) and the output head behind it in one launch (the hidden
+        // activation is never written)
+        if (o.type == OP_LINEAR && !save && G == 1 && M >= fuse_ln_min_rows() && !o.rowtab && o.res < 0 && (o.in_dim % GBK) == 0 &&
+            (o.out_dim == 256 || o.out_dim == 512) && i + 1 < (int)nd.ops.size() && nd.ops[i + 1].type == OP_HEAD &&
+            nd.ops[i + 1].src == out && nd.last_use[out] == i + 1 && nd.ops[i + 1].out_dim <= 4 && g_force_variant == 0) {
+            const Op& ho = nd.ops[i + 1];
+            RowLnArgs a{};
+            a.A = in; a.B = (o.ext ? Pext : P) + o.w; a.C = nullptr;
+            a.M = M; a.N = o.out_dim; a.K = o.in_dim; a.lda = o.in_dim; a.ldb = o.in_dim; a.ldc = o.out_dim;
+            a.bias = (o.ext ? Pext : P) + o.b; a.act = o.act;
+            a.headW = P + ho.w; a.headB = P + ho.b; a.headOut = c.Y[out + 1]; a.headN = ho.out_dim;
+            launch_rowln(a, st);
+            i += 1;
             continue;
         }
         if (o.type == OP_LINEAR) {
