@@ -909,6 +909,9 @@ struct LnArgs {
     int M, N;                  // N in {256, 512} (multiple of 256 handled as N/64 floats per lane, <= 8)
     long gX, gY, gP, gS;       // group strides: activations, params, stats
     DropArgs drop;             // dropout on the normalised output (policy head / critics: Linear-GELU-LN-Dropout)
+    // optional output head behind the norm: headOut[M, headN] = Y . headW^T + headB (headN <= 4), saving its launch
+    const float* headW; const float* headB; float* headOut; int headN;
+    long gHW, gHO;             // group strides of the head's parameters / output
 };
 template <int VPL>  // values per lane = N / 64
 __global__ void __launch_bounds__(256) layernorm_fwd_kernel(LnArgs a) {
@@ -937,6 +940,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(LnArgs a) {
     const float* gm = a.gamma + z * a.gP;
     const float* bt = a.beta + z * a.gP;
     float* y = a.Y + z * a.gY + (long)row * a.N;
+    float hacc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < VPL; i += 4) {
         const int c = (i / 4) * 256 + lane * 4;
@@ -952,6 +956,24 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(LnArgs a) {
             o.z *= drop_factor(a.drop, key, row, c + 2); o.w *= drop_factor(a.drop, key, row, c + 3);
         }
         *reinterpret_cast<float4*>(y + c) = o;
+        if (a.headW) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < a.headN) {
+                    const float4 w = *reinterpret_cast<const float4*>(a.headW + z * a.gHW + (long)j * a.N + c);
+                    hacc[j] += o.x * w.x + o.y * w.y + o.z * w.z + o.w * w.w;
+                }
+            }
+        }
+    }
+    if (a.headW) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) hacc[j] += __shfl_xor(hacc[j], s);
+        }
+        if (lane == 0)
+            for (int j = 0; j < a.headN; ++j) a.headOut[z * a.gHO + (long)row * a.headN + j] = hacc[j] + a.headB[z * a.gHW + j];
     }
     if (lane == 0 && a.mean) {
         a.mean[z * a.gS + row] = mean;
@@ -1009,6 +1031,9 @@ struct LnBwdArgs {
     float* colsum;              // optional [N]
     int M, N;
     long gA, gP, gS;            // strides: activations (dY, X, dX, Zp), params (gamma, dgamma, dbeta, colsum), stats
+    // dY given implicitly by an output head behind this norm: dY[m, c] = sum_j hdOut[m, j] hW[j, c] (hN <= 4), saving the
+    // head's dX launch; dY is then unused
+    const float* hdOut; const float* hW; int hN; long gHD, gHW;
     DropArgs dmask;             // this LayerNorm's output dropout: the incoming dY is masked first
     float* dXm; DropArgs omask; // optional second output dX * mask: the dZ of a producing Linear whose (dropped) output was
                                 // added to a residual (dX itself stays unmasked for the residual path)
@@ -1038,9 +1063,19 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(LnBwdArgs a) {
         for (int i = 0; i < VPL; i += 4) {
             const int c = (i / 4) * 256 + lane * 4;
             const float4 xv = *reinterpret_cast<const float4*>(a.X + off + c);
-            const float4 dv = *reinterpret_cast<const float4*>(a.dY + off + c);
             const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-            float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+            float ds[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.hW) {
+                for (int j = 0; j < a.hN; ++j) {
+                    const float dj = a.hdOut[z * a.gHD + (long)row * a.hN + j];
+                    const float4 w = *reinterpret_cast<const float4*>(a.hW + z * a.gHW + (long)j * a.N + c);
+                    ds[0] = fmaf(dj, w.x, ds[0]); ds[1] = fmaf(dj, w.y, ds[1]);
+                    ds[2] = fmaf(dj, w.z, ds[2]); ds[3] = fmaf(dj, w.w, ds[3]);
+                }
+            } else {
+                const float4 dv = *reinterpret_cast<const float4*>(a.dY + off + c);
+                ds[0] = dv.x; ds[1] = dv.y; ds[2] = dv.z; ds[3] = dv.w;
+            }
             if (a.dmask.ctr) {
                 const unsigned key = drop_key(a.dmask, (unsigned)z);
 #pragma unroll

@@ -437,10 +437,19 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
             a.mean = save ? c.mean[out] : nullptr; a.rstd = save ? c.rstd[out] : nullptr;
             a.M = M; a.N = o.out_dim; a.gX = gin; a.gY = c.gY[out]; a.gP = gP; a.gS = M;
             a.drop = drop_args(dc, i, o.drop);
+            bool head = false;  // the output head behind this norm rides along (its input, this norm's output, is still written)
+            if ((o.out_dim == 256 || o.out_dim == 512) && i + 1 < (int)nd.ops.size() && nd.ops[i + 1].type == OP_HEAD &&
+                nd.ops[i + 1].src == out && nd.ops[i + 1].out_dim <= 4) {
+                const Op& ho = nd.ops[i + 1];
+                a.headW = P + ho.w; a.headB = P + ho.b; a.headOut = c.Y[out + 1]; a.headN = ho.out_dim;
+                a.gHW = gP; a.gHO = c.gY[out + 1];
+                head = true;
+            }
             dim3 grid((M + 3) / 4, G), block(256);
             if (o.out_dim == 256) hipLaunchKernelGGL((layernorm_fwd_kernel<4>), grid, block, 0, st, a);
             else if (o.out_dim == 512) hipLaunchKernelGGL((layernorm_fwd_kernel<8>), grid, block, 0, st, a);
             else hipLaunchKernelGGL(layernorm_fwd_any_kernel, grid, block, 0, st, a);
+            if (head) i += 1;
         } else {
             HeadArgs a{};
             a.X = in; a.W = P + o.w; a.b = P + o.b; a.out = c.Y[out];
@@ -488,10 +497,11 @@ static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, l
             a.gD = c.gY[out]; a.gX = gin; a.gW = gP; a.gB = gP;
             HeadBwdArgs ad = a;  // dX uses the activation-gradient stride of the source buffer
             ad.gX = c.gY[o.src];
-            if (prod_act)
+            const bool into_ln = po && po->type == OP_LN && (po->out_dim == 256 || po->out_dim == 512);  // dX folded into the
+            if (prod_act)                                                                                 // norm's backward
                 hipLaunchKernelGGL(head_bwd_dx_act_kernel, dim3(M, G), dim3(256), 0, st, ad, c.Z[o.src], c.gY[o.src], po->act,
                                    prod_bias_grad, gG);
-            else
+            else if (!into_ln)
                 hipLaunchKernelGGL(head_bwd_dx_kernel, dim3(M, G), dim3(256), 0, st, ad);
             if (Gr) {
                 HeadBwdArgs aw = a;
@@ -508,6 +518,11 @@ static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, l
             a.M = M; a.N = o.out_dim;
             a.gA = c.gY[out]; a.gP = Gr ? gG : gP; a.gS = M;
             a.dmask = drop_args(dc, i, o.drop);  // this norm's output was dropped: mask the incoming gradient
+            if ((o.out_dim == 256 || o.out_dim == 512) && i + 1 < (int)nd.ops.size() && nd.ops[i + 1].type == OP_HEAD &&
+                nd.ops[i + 1].src == out) {  // dY = (head's output gradient) x (head weights), evaluated in place
+                const Op& ho = nd.ops[i + 1];
+                a.hdOut = c.dY[out + 1]; a.hW = P + ho.w; a.hN = ho.out_dim; a.gHD = c.gY[out + 1]; a.gHW = gP;
+            }
             if (dc && prod_lin && po->drop && po->res >= 0) {  // producer = Linear -> dropout -> + residual: its dZ is the masked dX
                 a.dXm = c.dYm[o.src];
                 a.omask = drop_args(dc, prod, po->drop);
