@@ -144,6 +144,10 @@ int tvc_env_fuel_thresholds(const tvc_env* env, int32_t* k_empty, int32_t* k_coa
  * The generator behind domain randomisation, observation noise and replay sampling; exposed for known-answer tests. */
 int tvc_debug_philox(const uint32_t* in_dev, uint32_t* out_dev, int32_t n, void* stream);
 
+/* Placement probe: out_dev uint32[2 * n_blocks] = {XCD id, HW_ID register} of every workgroup of one launch on `stream`
+ * (which compute units a CU-masked stream owns; used by the CU-partitioned train loop and its tests). */
+int tvc_debug_hwid(uint32_t* out_dev, int32_t n_blocks, void* stream);
+
 /* ------------------------------------------------------------------ SAC learner (K3-K7, K11) */
 
 typedef struct tvc_sac tvc_sac;

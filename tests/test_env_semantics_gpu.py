@@ -156,3 +156,18 @@ def test_n1_wrapper_with_curiosity_and_factories():
     assert r2 > e2 and (r2 - e2) < 1.0            # 0.01 * mse of an untrained forward model: small and positive
     env.close()
     ev.close()
+
+
+def test_workgroups_are_dealt_round_robin_over_the_eight_xcds():
+    """the placement assumption behind the XCD-aware tile order of the acting GEMM (tvc_nn_kernels.h: gemm_kernel): blocks b and
+    b + 8 of a launch share an XCD (its L2), all 8 XCDs take part"""
+    from tvc_ai_amd import _native as nat
+    L = nat.load()
+    nb = 2048
+    out = torch.zeros(2 * nb, dtype=torch.int32, device="cuda")
+    nat.check(L.tvc_debug_hwid(out.data_ptr(), nb, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    xcc = (out.cpu().numpy().astype(np.uint32).reshape(nb, 2)[:, 0] & 0xF).astype(np.int64)
+    assert set(xcc.tolist()) == set(range(8))
+    assert (np.bincount(xcc, minlength=8) == nb // 8).all()
+    assert (xcc[8:] == xcc[:-8]).mean() > 0.99   # same XCD every 8 blocks

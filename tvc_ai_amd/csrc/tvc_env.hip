@@ -204,6 +204,14 @@ __global__ void env_import_kernel(EnvBuf b, int W, const float* dyn, const int* 
     store_regs<true, true>(r, hw, b, i, 100);
 }
 
+__global__ void hwid_debug_kernel(unsigned* __restrict__ out) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    // keep the block alive for a moment so that blocks spread over the allowed CUs instead of reusing the first one
+    for (int i = 0; i < 200; ++i) __builtin_amdgcn_s_sleep(10);
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = xcc; out[2 * blockIdx.x + 1] = hw; }
+}
 __global__ void philox_debug_kernel(const unsigned* __restrict__ in, unsigned* __restrict__ out, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -466,6 +474,15 @@ int tvc_env_info(tvc_env* e, float* info_dev, void* stream) {
 int tvc_debug_philox(const uint32_t* in_dev, uint32_t* out_dev, int32_t n, void* stream) {
     if (!in_dev || !out_dev || n < 1) return tvc::set_error(TVC_EINVAL, "bad argument");
     hipLaunchKernelGGL(philox_debug_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, in_dev, out_dev, n);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Where a launch's workgroups ran: out[2b] = XCD id (HW_REG_XCC_ID), out[2b + 1] = HW_REG_HW_ID (CU / SE bits) of block b.
+// Used to find out which compute units a CU-masked stream (hipExtStreamCreateWithCUMask) really owns.
+int tvc_debug_hwid(uint32_t* out_dev, int32_t n_blocks, void* stream) {
+    if (!out_dev || n_blocks < 1) return tvc::set_error(TVC_EINVAL, "bad argument");
+    hipLaunchKernelGGL(hwid_debug_kernel, dim3(n_blocks), dim3(64), 0, (hipStream_t)stream, out_dev);
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }
