@@ -1,8 +1,12 @@
 // Device kernels of the SAC learner (fp32, MFMA f32 16x16x4 for every GEMM-shaped contraction).
 //
 // They replace the PyTorch eager op sequences of the reference's agent/multi_algorithm_agent.py:
-//   nn.Linear (+bias, GELU / ReLU, residual)            -> gemm_kernel (fused epilogues)
+//   nn.Linear (+bias, GELU / ReLU, residual)            -> gemm_kernel (64x64 tiles, fused epilogues; acting, M = envs)
+//   nn.Linear + nn.LayerNorm (+ output head)            -> gemm_rowln_kernel (32 complete rows per workgroup; acting)
+//   nn.Linear at batch size, forward / dX / dW          -> gemm_skinny_kernel, gemm_skinny_bwd_kernel (split-K, no LDS staging)
+//   nn.Linear with <= 16 inputs (obs / [s | a] layers)  -> thin_fwd / thin_fwd_ln / thin_wgrad / thin_dgrad_kernel (plain FMA)
 //   nn.LayerNorm forward / backward                      -> layernorm_fwd_kernel / layernorm_bwd_kernel
+//   nn.Dropout of the train-mode update                  -> DropArgs masks inside the epilogues above
 //   Linear(hidden -> 2A) / Linear(hidden -> 1) heads     -> head_fwd_kernel / head_bwd_kernel (dot-reductions, no MFMA)
 //   torch.optim.Adam.step, Polyak soft update            -> adam_dev_kernel (tvc_sac.hip) / polyak_kernel
 // Numerics: v_mfma_f32_16x16x4_f32 is an exact-f32 k-ordered fma chain (no TF32 on gfx950), so results

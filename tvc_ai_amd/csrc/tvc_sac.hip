@@ -2,7 +2,13 @@
 // tvc_nn_kernels.h, the SAC loss/elementwise kernels, Adam/Polyak, and the C ABI (include/tvc_native.h).
 //
 // Replaces MultiAlgorithmAgent._create_sac_agent / get_action (policy part) / update / _update_sac /
-// PhysicsInformedLoss, agent/multi_algorithm_agent.py:587-627, 736-809, 868-912, 950-1016, 236-285.
+// PhysicsInformedLoss, agent/multi_algorithm_agent.py:587-627, 736-809, 868-912, 950-1016, 236-285; further down the
+// small-MLP handle behind CuriosityModule (env/enhanced_rocket_tvc_env.py:226-269), SafetyLayer (agent/...:287-351)
+// and the goal policy of HierarchicalAgent (agent/...:353-417).
+//
+// Layout of this file: net description (Op / NetDef, build_actor / build_critic / derive_infer: the acting net with
+// W_o W_v and the embedding folded) -> executor (net_forward / net_backward: which kernel runs each op, incl. the
+// fused acting launches and the train-mode dropout sites) -> SAC elementwise kernels -> handle + C ABI.
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
