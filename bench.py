@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per K steps")
     ap.add_argument("--graph", action="store_true", help="train: capture the K steps in one hipGraph (default: eager; the host "
                                                          "stays ahead of the device, both measure the same)")
+    ap.add_argument("--steps-per-launch", type=int, default=1, help="physics: T env steps per kernel launch with pre-supplied actions "
+                                                                    "(tvc_env_step_many, the tests/benchmark.py:40-60 procedure); --steps must be a multiple")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample length (0 = skip)")
     ap.add_argument("--roofline-envs", type=int, default=1 << 22, help="bandwidth-regime size for the extra roofline point")
     return ap.parse_args()
@@ -217,8 +219,21 @@ def main():
         n_act = 64
         acts = (torch.rand((n_act, n, 2), device=device, generator=g) * 2 - 1).contiguous()
 
-        def step_fn(k):
-            env.step(acts[k % n_act])
+        T = max(1, args.steps_per_launch)
+        if T > 1:  # state stays in registers across T steps of one launch; outputs of all T steps are written
+            if K % T or W % T:
+                raise SystemExit("--steps and --warmup must be multiples of --steps-per-launch")
+            outs = (torch.empty((T, n, 10), device=device), torch.empty((T, n), device=device),
+                    torch.empty((T, n), dtype=torch.uint8, device=device), torch.empty((T, n), dtype=torch.uint8, device=device))
+            acts_t = acts[:T].contiguous() if T <= n_act else (torch.rand((T, n, 2), device=device, generator=g) * 2 - 1).contiguous()
+
+            def step_fn(k):
+                if k % T == 0:
+                    env.step_many(acts_t, out=outs)
+            extra["steps_per_launch"] = T
+        else:
+            def step_fn(k):
+                env.step(acts[k % n_act])
 
     for k in range(W):
         step_fn(k)

@@ -14,6 +14,8 @@ run --workload physics --envs-per-gpu 4096 --steps 2000 --warmup 100
 run --workload physics --envs-per-gpu 8192 --steps 2000 --warmup 100
 run --workload physics --envs-per-gpu 65536 --steps 2000 --warmup 100
 run --workload physics --envs-per-gpu 4194304 --steps 100 --warmup 10
+run --workload physics --envs-per-gpu 4096 --steps 1920 --warmup 192 --steps-per-launch 64
+run --workload physics --envs-per-gpu 65536 --steps 1920 --warmup 192 --steps-per-launch 64
 run --workload train --envs-per-gpu 4096 --steps 300 --warmup 30
 run --workload train --envs-per-gpu 8192 --steps 300 --warmup 30
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30
