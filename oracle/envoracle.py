@@ -82,6 +82,8 @@ def lib():
         L.tvc_oracle_reset.argtypes = [C.POINTER(Env), C.POINTER(Params)]
         L.tvc_oracle_observe.argtypes = [C.POINTER(Env), C.POINTER(Params), C.POINTER(C.c_float)]
         L.tvc_oracle_physics.argtypes = [C.POINTER(Env), C.POINTER(Params), C.POINTER(C.c_double)]
+        L.tvc_oracle_wrench.argtypes = [C.POINTER(Env), C.POINTER(Params), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.tvc_oracle_scalars_from_state.argtypes = [C.POINTER(Env), C.POINTER(Scalars)]
         L.tvc_oracle_logic.argtypes = [C.POINTER(Env), C.POINTER(Params), C.POINTER(Scalars),
                                        C.POINTER(C.c_double), C.POINTER(Out)]
@@ -147,6 +149,13 @@ class OracleEnv:
     def physics(self, action):
         a, ap = _dvec(action)
         lib().tvc_oracle_physics(C.byref(self.e), C.byref(self.p), ap)
+
+    def wrench(self, action):
+        """external (F, tau) about the COM for the CLIPPED action, as step() would assemble it now"""
+        a, ap = _dvec(np.clip(np.asarray(action, dtype=np.float64), -1.0, 1.0))
+        F, tau = (C.c_double * 3)(), (C.c_double * 3)()
+        lib().tvc_oracle_wrench(C.byref(self.e), C.byref(self.p), ap, F, tau)
+        return np.array(F), np.array(tau)
 
     def scalars(self):
         sc = Scalars()

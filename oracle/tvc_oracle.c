@@ -315,17 +315,19 @@ static void substep(tvc_oracle_env* e, const tvc_oracle_params* p, const double 
     for (int i = 0; i < 4; ++i) e->quat[i] = qn[i] / l;
 }
 
-/* ref: env/enhanced_rocket_tvc_env.py:520-585 (_apply_enhanced_control, _apply_aerodynamics)
-   then :477 p.stepSimulation (n_sub substeps). action is already clipped to [-1,1]. */
-void tvc_oracle_physics(tvc_oracle_env* e, const tvc_oracle_params* p, const double action[2]) {
+/* ref: env/enhanced_rocket_tvc_env.py:520-585 (_apply_enhanced_control, _apply_aerodynamics): the EXTERNAL wrench
+   the reference hands to pybullet through applyExternalForce / applyExternalTorque, summed about the COM
+   (world gravity of p.setGravity is NOT part of it).  Does not touch the env (fuel is decremented by the caller).
+   PINNED by tests/golden/step_ref_*.npz: the reference's own step() driven over a recording pybullet stand-in
+   (tests/golden/gen_step_golden.py).  action is already clipped to [-1,1]. */
+void tvc_oracle_wrench(const tvc_oracle_env* e, const tvc_oracle_params* p, const double action[2], double F[3],
+                       double tau[3]) {
     double R[9];
     tvc_oracle_quat_to_matrix(e->quat, R);
-    double F[3] = {0.0, 0.0, -p->gravity * p->mass}; /* explicit gravity force -9.81*mass at COM, ref :524-527 */
-    double tau[3] = {0.0, 0.0, 0.0};
+    F[0] = 0.0; F[1] = 0.0; F[2] = -p->gravity * p->mass; /* explicit gravity force -9.81*mass at COM, ref :524-527 */
+    tau[0] = tau[1] = tau[2] = 0.0;
 
-    if (e->fuel > 0.0) { /* ref :530 */
-        double f = e->fuel - 0.001;
-        e->fuel = f > 0.0 ? f : 0.0; /* max(0, fuel - 0.001) ref :533 */
+    if (e->fuel > 0.0) { /* ref :530 (tested BEFORE the decrement of :533) */
         double pitch = action[0] * GIMBAL_RAD; /* pitch_angle, yaw_angle = self.gimbal_angles ref :537 */
         double yaw = action[1] * GIMBAL_RAD;
         double Tl[3] = {p->thrust * sin(yaw), p->thrust * sin(pitch), p->thrust * cos(pitch) * cos(yaw)}; /* ref :539-543 */
@@ -350,6 +352,16 @@ void tvc_oracle_physics(tvc_oracle_env* e, const tvc_oracle_params* p, const dou
     for (int i = 0; i < 3; ++i) tau[i] += -adamp * e->omega[i];
     /* build-defined DR: constant wind force */
     for (int i = 0; i < 3; ++i) F[i] += p->wind[i];
+}
+
+/* wrench (above), fuel bookkeeping ref :530-533, then :477 p.stepSimulation (n_sub substeps). */
+void tvc_oracle_physics(tvc_oracle_env* e, const tvc_oracle_params* p, const double action[2]) {
+    double F[3], tau[3];
+    tvc_oracle_wrench(e, p, action, F, tau);
+    if (e->fuel > 0.0) {
+        double f = e->fuel - 0.001;
+        e->fuel = f > 0.0 ? f : 0.0; /* max(0, fuel - 0.001) ref :533 */
+    }
     /* world gravity p.setGravity(0,0,-9.81) ref :338 -- ASSUMPTION(bullet): added as m*g base force */
     F[2] += -p->gravity * p->mass;
 
