@@ -131,6 +131,14 @@ int tvc_env_export_state(tvc_env* env, float* dyn_dev, int32_t* aux_dev, float* 
 int tvc_env_import_state(tvc_env* env, const float* dyn_dev, const int32_t* aux_dev, const float* pa_dev,
                          const float* par_dev, const float* hist_dev, void* stream);
 
+/* info['reward_components'] of step() (env/...:491-493, 514; MultiObjectiveReward.compute_reward :97-112): when comps_dev is
+ * non-NULL every following tvc_env_step also writes comps_dev float[N,12] =
+ *   mission_completion, safety_compliance, fuel_efficiency, stability_bonus, control_smoothness, altitude_maintenance,
+ *   crash_penalty, excessive_tilt, control_saturation (0 when the penalty did not fire), anti-hacking adjustment (:209-224),
+ *   unclipped total, penalty presence mask (bit 0 crash, 1 tilt, 2 saturation: the reference's dict only holds fired penalties).
+ * NULL (default) switches it off.  The pointer is caller-owned device memory that must outlive the steps. */
+int tvc_env_set_components_out(tvc_env* env, float* comps_dev);
+
 /* info dict of _get_enhanced_info (env/...:723-742) as tensors:
  *   info_dev float[N,8]: x, y, altitude, tilt_angle_deg, angular_velocity_mag, fuel, phase idx,
  *                        success_criteria_met(last 10) */

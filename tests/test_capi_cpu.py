@@ -33,18 +33,58 @@ def test_library_exports_every_declared_symbol():
     assert L.tvc_abi_version() == 1
 
 
-def test_ctypes_struct_matches_header(tmp_path):
-    from tvc_ai_amd import _native as nat
-    src = tmp_path / "sz.c"
+def _c_layout(tmp_path, struct, fields):
+    """sizeof + offsetof of every field, from gcc and the header itself"""
+    src = tmp_path / f"{struct}.c"
+    body = "".join(f'printf("%zu\\n", offsetof({struct}, {f}));' for f in fields)
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tvc_native.h"\n'
-                   'int main(){printf("%zu %zu %zu\\n", sizeof(tvc_env_cfg), offsetof(tvc_env_cfg, seed),'
-                   ' offsetof(tvc_env_cfg, init_quat));return 0;}\n')
-    exe = tmp_path / "sz"
+                   f'int main(){{printf("%zu\\n", sizeof({struct}));{body}return 0;}}\n')
+    exe = tmp_path / struct
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
-    size, off_seed, off_q = map(int, subprocess.check_output([str(exe)]).split())
-    assert size == C.sizeof(nat.EnvCfg)
-    assert off_seed == nat.EnvCfg.seed.offset
-    assert off_q == nat.EnvCfg.init_quat.offset
+    vals = list(map(int, subprocess.check_output([str(exe)]).split()))
+    return vals[0], dict(zip(fields, vals[1:]))
+
+
+@pytest.mark.parametrize("struct,mirror", [("tvc_env_cfg", "EnvCfg"), ("tvc_sac_cfg", "SacCfg")])
+def test_ctypes_struct_matches_header(tmp_path, struct, mirror):
+    """size and EVERY field offset of the ctypes mirrors against the C structs of include/tvc_native.h; also that the
+    mirror lists the header's fields in the header's order (a renamed / reordered field is caught, not only a resized one)."""
+    from tvc_ai_amd import _native as nat
+    cls = getattr(nat, mirror)
+    fields = [f[0] for f in cls._fields_]
+    hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, flags=re.S).group(1)
+    declared = []
+    for stmt in body.split(";"):
+        stmt = stmt.strip()
+        if stmt:
+            declared += [re.sub(r"\[.*\]", "", n.strip()) for n in re.sub(r"^[a-z0-9_]+\s+", "", stmt).split(",")]
+    assert declared == fields, (declared, fields)
+    size, offs = _c_layout(tmp_path, struct, fields)
+    assert size == C.sizeof(cls)
+    for f in fields:
+        assert offs[f] == getattr(cls, f).offset, f
+
+
+def test_dropin_tree_resolves_the_imports_of_train_py():
+    """scripts/train.py:44-45 with <repo>/dropin on sys.path: module paths, class names, MissionPhase order (index / 7 is obs[8])."""
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "from env.enhanced_rocket_tvc_env import EnhancedRocketTVCEnv, MissionPhase\n"
+            "from agent.multi_algorithm_agent import MultiAlgorithmAgent\n"
+            "import env, agent\n"
+            "assert [p.value for p in MissionPhase] == ['boost', 'coast', 'landing', 'touchdown', 'hover', 'complete', 'failed']\n"
+            "assert env.EnhancedRocketTVCEnv is EnhancedRocketTVCEnv and agent.MultiAlgorithmAgent is MultiAlgorithmAgent\n"
+            "for n in ('make_training_env', 'make_evaluation_env', 'make_debug_env', 'MissionPhase'): assert hasattr(env, n), n\n"
+            "for n in ('reset', 'step', 'close', 'render'): assert hasattr(EnhancedRocketTVCEnv, n), n\n"
+            "for n in ('select_algorithm', 'get_action', 'update', 'update_performance', 'save_checkpoint', 'load_checkpoint', 'to'):\n"
+            "    assert hasattr(MultiAlgorithmAgent, n), n\n"
+            "import inspect\n"
+            "assert list(inspect.signature(EnhancedRocketTVCEnv.__init__).parameters)[1:8] == ['config', 'max_episode_steps', "
+            "'render_mode', 'enable_hierarchical', 'enable_curiosity', 'enable_physics_informed', 'debug']\n"
+            "assert list(inspect.signature(MultiAlgorithmAgent.__init__).parameters)[1:4] == ['obs_dim', 'action_dim', 'config']\n"
+            "print('ok')\n") % (os.path.join(ROOT, "dropin"), ROOT)
+    out = subprocess.check_output([sys.executable, "-c", code], cwd="/tmp")
+    assert out.strip().endswith(b"ok")
 
 
 def test_default_cfg_matches_reference_constants():

@@ -1,0 +1,210 @@
+"""HIP env vs the REFERENCE'S OWN step() outputs (tests/golden/step_ref_*.npz, made by tests/golden/gen_step_golden.py from the
+reference module over a scripted pybullet stand-in).
+
+Two kinds of comparison, both through the C ABI:
+  * teacher-forced: before every step the kernel's dynamic state is set to the pose the reference saw (fp32 of the script), so
+    every step checks the kernel's one-step map -- wrench, 4 substeps, observation, phase / success / reward / termination, the
+    reward components -- against the reference's outputs without trajectory drift.  Tolerances: observation 2e-6 abs (fp32
+    rounding of a one-step map), reward and components 2e-4 * max(1, |ref|) (exp(-10 (tilt - 0.087)) amplifies), flags exact.
+  * free-running: the N = 1 drop-in wrapper, imported through the dropin/ module paths scripts/train.py uses, replays the same
+    actions from reset with the curiosity bonus on.  fp32 vs fp64 drift: <= 1e-4 before the first ground contact; after it the
+    build-defined contact model is a discontinuous map and the tolerance is the measured fork statistics (stated at the assert).
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests import parity_log
+from tests.test_step_golden import SCENARIOS, load
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+KEYS = ["mission_completion", "safety_compliance", "fuel_efficiency", "stability_bonus", "control_smoothness",
+        "altitude_maintenance", "crash_penalty", "excessive_tilt", "control_saturation"]
+INIT = np.array([0, 0, 1.0, 0, 0, 0, 1.0, 0, 0, 0, 0, 0, 0], dtype=np.float64)
+
+
+def _mod(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(HERE, "golden", name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def curiosity_state_dict():
+    rec, gs = _mod("gen_sac_golden"), _mod("gen_step_golden")
+    return {k: torch.from_numpy(v) for k, v in rec.fill_params(gs.curiosity_named(), np.random.default_rng(gs.CUR_SEED)).items()}
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_teacher_forced_step_matches_the_reference(name):
+    from tvc_ai_amd import VecRocketTVCEnv
+    g = load(name)
+    T = g["action"].shape[0]
+    # dr_enabled with all ranges zero: the DR instantiation reads the per-env thrust scale, which carries the scenario's thrust
+    env = VecRocketTVCEnv(1, device="cuda:0", max_episode_steps=int(g["max_episode_steps"]), contact=1, auto_reset=0,
+                          distinct_window=1000, dr_enabled=1, dr_mass_var=0.0, dr_thrust_std=0.0, dr_cg_max=0.0, dr_wind_std=0.0,
+                          dr_init_tilt_max=0.0, dr_obs_noise_std=0.0)
+    comps = env.enable_reward_components()
+    worst = dict(obs=0.0, reward=0.0, comps=0.0, info=0.0, post=0.0)
+    flips = 0
+    pre = INIT
+    for t in range(T):
+        if g["reset_before"][t]:
+            obs0, _ = env.reset()
+            assert np.array_equal(obs0[0].cpu().numpy(), g["reset_obs"][t]), t
+            pre = INIT
+        par = np.array([[1.0, g["thrust_t"][t] / 35.0, 0, 0, 0, 0, 0, 0]], dtype=np.float32)
+        env.import_state(dyn=pre[None].astype(np.float32), params=par)
+        a = torch.from_numpy(g["action"][t][None].astype(np.float32)).cuda()
+        obs, rew, term, trunc, _ = env.step(a)
+        o = obs[0].cpu().numpy()
+        c = comps[0].cpu().numpy()
+        st = env.export_state()
+        aux = st["aux"][0].cpu().numpy()
+        info = env.info_tensor()[0].cpu().numpy()
+        ref_c = np.nan_to_num(g["comps"][t][:9])
+        cur = 0.0 if np.isnan(g["comps"][t][9]) else g["comps"][t][9]
+        ref_r = g["reward"][t] - cur
+        disc_ok = (bool(term[0]) == bool(g["term"][t]) and bool(trunc[0]) == bool(g["trunc"][t]) and aux[1] == g["info_phase"][t]
+                   and bool(aux[2]) == bool(g["info_success"][t]) and aux[0] == g["info_step"][t]
+                   and bool(info[7] > 0.5) == bool(g["info_criteria10"][t]))
+        if not disc_ok:  # only legitimate when a reference-side scalar sits on a threshold to within fp32 resolution
+            near = min(abs(g["info_altitude"][t] - x) for x in (0.1, 0.2, 0.5, 1.0, 2.0, 5.0, 20.0)) < 2e-6 or \
+                min(abs(np.radians(g["info_tilt_deg"][t]) - x) for x in (0.087, 0.52)) < 2e-6 or abs(g["info_omega"][t] - 0.1) < 2e-6
+            assert near, (name, t, aux.tolist(), int(g["info_phase"][t]), bool(g["term"][t]))
+            flips += 1
+            break
+        worst["obs"] = max(worst["obs"], float(np.abs(o - g["obs"][t]).max()))
+        worst["reward"] = max(worst["reward"], abs(float(rew[0]) - ref_r) / max(1.0, abs(ref_r)))
+        worst["comps"] = max(worst["comps"], float((np.abs(c[:9] - ref_c) / np.maximum(1.0, np.abs(ref_c))).max()))
+        present = int(c[11])
+        assert [bool(present >> k & 1) for k in range(3)] == [not np.isnan(g["comps"][t][6 + k]) for k in range(3)], t
+        worst["post"] = max(worst["post"], float(np.abs(st["dyn"][0].cpu().numpy() - g["post"][t]).max()))
+        for mine, ref in ((info[2], g["info_altitude"][t]), (info[3], g["info_tilt_deg"][t]), (info[4], g["info_omega"][t]),
+                          (info[5], g["info_fuel"][t])):
+            worst["info"] = max(worst["info"], abs(float(mine) - ref) / max(1.0, abs(ref)))
+        pre = g["post"][t]
+    parity_log.record(f"step_golden_teacher_forced[{name}]", steps=T, threshold_flips=flips, **worst)
+    print(name, worst, "flips", flips)
+    assert flips == 0
+    assert worst["obs"] <= 2e-6 and worst["post"] <= 5e-6
+    assert worst["reward"] <= 2e-4 and worst["comps"] <= 2e-4 and worst["info"] <= 2e-5
+    env.close()
+
+
+def _dropin_modules():
+    for p in (os.path.join(ROOT, "dropin"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from env.enhanced_rocket_tvc_env import EnhancedRocketTVCEnv, MissionPhase  # the import line of scripts/train.py:44
+    from agent.multi_algorithm_agent import MultiAlgorithmAgent                  # scripts/train.py:45
+    return EnhancedRocketTVCEnv, MissionPhase, MultiAlgorithmAgent
+
+
+@pytest.mark.parametrize("name,thrust", [("nominal", 35.0), ("hover", 39.5), ("success", 39.24)])
+def test_free_running_dropin_wrapper_matches_the_reference(name, thrust):
+    """reset() / step() of the N = 1 wrapper, numpy in / out like the reference, against the reference's outputs, INCLUDING the
+    steps after ground contact (the round-1 test stopped comparing at altitude 0.58)."""
+    EnhancedRocketTVCEnv, MissionPhase, _ = _dropin_modules()
+    g = load(name)
+    T = g["action"].shape[0]
+    env = EnhancedRocketTVCEnv(config={"tvc_native": {"thrust": thrust}}, max_episode_steps=int(g["max_episode_steps"]),
+                               enable_curiosity=True)
+    env._curiosity.load_state_dict(curiosity_state_dict())
+    pre_err, post_err, rew_err_pre, rew_err_post = [], [], [], []
+    # resets follow the golden's schedule (the wrapper has no auto-reset, like the reference): a forked episode is
+    # re-synchronised at the next reset
+    mism_steps, episodes, ep_forked, in_contact, forked = 0, 0, 0, False, False
+    for t in range(T):
+        if g["reset_before"][t]:
+            obs, info = env.reset(seed=7)
+            assert obs.dtype == np.float32 and np.array_equal(obs, g["reset_obs"][t])
+            assert env.current_phase is MissionPhase.BOOST
+            episodes += 1
+            ep_forked += int(forked)
+            in_contact = forked = False
+        obs, reward, term, trunc, info = env.step(g["action"][t])
+        assert isinstance(reward, float) and isinstance(term, bool) and isinstance(trunc, bool) and obs.dtype == np.float32
+        in_contact = in_contact or g["info_altitude"][t] < 0.56  # base disc (half length 0.5 + radius 0.05) may touch
+        e_obs = float(np.abs(obs - g["obs"][t]).max())
+        e_rew = abs(reward - g["reward"][t]) / max(1.0, abs(g["reward"][t]))
+        same_flags = term == bool(g["term"][t]) and trunc == bool(g["trunc"][t])
+        if not forked:
+            (post_err if in_contact else pre_err).append(e_obs)
+            (rew_err_post if in_contact else rew_err_pre).append(e_rew)
+            if not in_contact:
+                assert same_flags and info["mission_phase"] == list(MissionPhase)[int(g["info_phase"][t])].value, (name, t)
+                assert info["mission_successful"] == bool(g["info_success"][t]), (name, t)
+                assert set(k for k in info["reward_components"]) == \
+                    set(k for i, k in enumerate(KEYS + ["curiosity"]) if not np.isnan(g["comps"][t][i])), (name, t)
+        if not same_flags or e_obs > 5e-3:
+            # the free-running fp32 trajectory left the fp64 one (only legitimate after contact): re-synchronise at the next reset
+            assert in_contact, (name, t, e_obs, term, trunc)
+            if not forked:
+                mism_steps += 1
+            forked = True
+    ep_forked += int(forked)
+    res = dict(steps=T, episodes=episodes, episodes_forked_after_contact=ep_forked,
+               pre_contact_steps=len(pre_err), pre_contact_obs_err=max(pre_err) if pre_err else 0.0,
+               pre_contact_reward_err=max(rew_err_pre) if rew_err_pre else 0.0,
+               post_contact_steps_compared=len(post_err), post_contact_obs_err_max=max(post_err) if post_err else 0.0,
+               post_contact_obs_err_median=float(np.median(post_err)) if post_err else 0.0,
+               post_contact_reward_err_max=max(rew_err_post) if rew_err_post else 0.0)
+    parity_log.record(f"step_golden_free_running_wrapper[{name}]", **res)
+    print(name, res)
+    # before ground contact: north_star's 1e-4 (fp32 kernel vs the fp64 script the reference saw)
+    assert res["pre_contact_obs_err"] <= 1e-4 and res["pre_contact_reward_err"] <= 2e-3
+    # after contact: the impulse model is discontinuous (which substep touches first, stick vs slip), so an fp32 run of the SAME
+    # model can leave the fp64 one; measured: the median stays at fp32 level, forks are a minority of episodes
+    assert res["post_contact_obs_err_median"] <= 2e-4
+    assert ep_forked <= max(1, episodes // 3), res
+    env.close()
+
+
+def test_run_episode_shaped_loop_through_the_dropin_module_paths():
+    """The loop of scripts/train.py:535-620 (reset, select_algorithm, get_action on a [1,10] tensor, step, B = 1 update with a
+    BoolTensor `dones`, update_performance) through `env.enhanced_rocket_tvc_env` / `agent.multi_algorithm_agent`."""
+    EnhancedRocketTVCEnv, MissionPhase, MultiAlgorithmAgent = _dropin_modules()
+    config = {"hierarchical_rl": {"enabled": True}, "safety": {"safety_layer": {"enabled": True}},
+              "physics_informed": {"enabled": True}, "tvc_native": {"batch_size": 1, "max_act_rows": 16}}
+    env = EnhancedRocketTVCEnv(config=config, max_episode_steps=1000, render_mode=None, enable_hierarchical=True,
+                               enable_curiosity=True, enable_physics_informed=True, debug=False)
+    obs_dim, action_dim = env.observation_space.shape[0], env.action_space.shape[0]
+    agent = MultiAlgorithmAgent(obs_dim, action_dim, config)
+    agent = agent.to(torch.device("cuda"))
+    total_timesteps, losses = 0, {}
+    for episode in range(3):
+        obs, info = env.reset()
+        algorithm = agent.select_algorithm()
+        episode_reward = 0.0
+        while True:
+            obs_tensor = torch.FloatTensor(obs).unsqueeze(0).cuda()
+            action, action_info = agent.get_action(obs_tensor)
+            if action.ndim > 1:
+                action = action.flatten()
+            next_obs, reward, terminated, truncated, step_info = env.step(action)
+            for k in ("mission_successful", "tilt_angle_deg", "angular_velocity_mag", "altitude", "mission_phase",
+                      "fuel_remaining", "reward_components", "position", "step", "success_criteria_met"):
+                assert k in step_info, k
+            assert step_info["mission_phase"] in [p.value for p in MissionPhase]
+            batch = {"states": torch.FloatTensor(obs).unsqueeze(0).cuda(), "actions": torch.FloatTensor(action).unsqueeze(0).cuda(),
+                     "rewards": torch.FloatTensor([reward]).cuda(), "next_states": torch.FloatTensor(next_obs).unsqueeze(0).cuda(),
+                     "dones": torch.BoolTensor([terminated or truncated]).cuda()}
+            losses = agent.update(batch, algorithm="sac")
+            assert "error" not in losses and all(np.isfinite(v) for v in losses.values()), losses
+            episode_reward += reward
+            total_timesteps += 1
+            if terminated or truncated:
+                break
+            obs = next_obs
+        agent.update_performance(algorithm, episode_reward)
+    assert total_timesteps > 30 and {"q1_loss", "q2_loss", "policy_loss"} <= set(losses)
+    assert len(agent.performance_history[algorithm]) == 3
+    env.close()

@@ -5,8 +5,10 @@ SAC learner as hand-written HIP kernels behind the reference's Python surface.
 ``tvc-ai_amd``.)
 """
 from .env import (EnhancedRocketTVCEnv, VecRocketTVCEnv, make_debug_env, make_enhanced_tvc_env,  # noqa: F401
-                  make_evaluation_env, make_training_env, CURRICULUM_STAGES, PHASE_NAMES)
+                  make_evaluation_env, make_training_env, CURRICULUM_STAGES, PHASE_NAMES, MissionPhase, MissionSuccess,
+                  SuccessCriteria)
 from ._native import TvcError  # noqa: F401
 
 __all__ = ["EnhancedRocketTVCEnv", "VecRocketTVCEnv", "make_training_env", "make_evaluation_env",
-           "make_debug_env", "make_enhanced_tvc_env", "TvcError", "CURRICULUM_STAGES", "PHASE_NAMES"]
+           "make_debug_env", "make_enhanced_tvc_env", "TvcError", "CURRICULUM_STAGES", "PHASE_NAMES", "MissionPhase",
+           "MissionSuccess", "SuccessCriteria"]

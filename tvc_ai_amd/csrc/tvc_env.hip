@@ -46,7 +46,7 @@ template <bool W10, bool DR>
 __global__ void __launch_bounds__(kMaxBlock)
 env_step_kernel(EnvBuf b, DevCfg c, DrCfg d, const float* __restrict__ act, float* __restrict__ obs,
                 float* __restrict__ rew, unsigned char* __restrict__ term, unsigned char* __restrict__ trunc,
-                float* __restrict__ final_obs, int n_steps) {
+                float* __restrict__ final_obs, float* __restrict__ comps, int n_steps) {
     __shared__ __attribute__((aligned(16))) float tile[kMaxBlock * 10];
     const int row0 = blockIdx.x * blockDim.x;
     const int i = row0 + threadIdx.x;
@@ -74,6 +74,12 @@ env_step_kernel(EnvBuf b, DevCfg c, DrCfg d, const float* __restrict__ act, floa
             trunc[toff + i] = (unsigned char)o.trunc;
 #pragma unroll
             for (int k = 0; k < 10; ++k) tile[threadIdx.x * 10 + k] = o.obs[k];
+            if (comps != nullptr) {  // uniform branch; info['reward_components'] of the N = 1 surface (ref :514)
+                float4* cp = reinterpret_cast<float4*>(comps + (toff + i) * 12);
+                cp[0] = make_float4(o.comps[0], o.comps[1], o.comps[2], o.comps[3]);
+                cp[1] = make_float4(o.comps[4], o.comps[5], o.comps[6], o.comps[7]);
+                cp[2] = make_float4(o.comps[8], o.comps[9], o.comps[10], o.comps[11]);
+            }
         }
         if (final_obs != nullptr) {
             __syncthreads();
@@ -257,6 +263,7 @@ struct tvc_env {
     int device;
     int W;
     void* slab;
+    float* comps_out;  // optional [N,12] reward-component sink (tvc_env_set_components_out)
 };
 
 static int fuel_threshold(double thr, bool strict_less) {
@@ -343,7 +350,7 @@ int tvc_env_create(const tvc_env_cfg* cfg, int32_t n_envs, int32_t device, tvc_e
     TVC_HIP_CHECK(hipSetDevice(device));
     tvc_env* e = new (std::nothrow) tvc_env();
     if (!e) return tvc::set_error(TVC_ENOMEM, "host allocation failed");
-    e->cfg = *cfg; e->n = n_envs; e->device = device; e->W = cfg->distinct_window;
+    e->cfg = *cfg; e->n = n_envs; e->device = device; e->W = cfg->distinct_window; e->comps_out = nullptr;
     build_devcfg(*cfg, e->W, e->dc, e->dr);
     const int np = tvc::ceil_div(n_envs, 64) * 64;
     const size_t bytes = (size_t)np * kCellGroups * sizeof(float4) + (e->W == 1000 ? (size_t)np * 1000 * sizeof(float) : 0);
@@ -421,7 +428,7 @@ static int launch_step(tvc_env* e, int n_steps, const float* act, float* obs, fl
     hipStream_t st = (hipStream_t)stream;
 #define TVC_LAUNCH_STEP(A, B)                                                                                         \
     hipLaunchKernelGGL((env_step_kernel<A, B>), grid, block, 0, st, e->buf, e->dc, e->dr, act, obs, rew, term, trunc, \
-                       final_obs, n_steps)
+                       final_obs, n_steps == 1 ? e->comps_out : nullptr, n_steps)
     if (w10 && !dr) TVC_LAUNCH_STEP(true, false);
     else if (w10 && dr) TVC_LAUNCH_STEP(true, true);
     else if (!w10 && !dr) TVC_LAUNCH_STEP(false, false);
@@ -457,6 +464,13 @@ int tvc_env_import_state(tvc_env* e, const float* dyn, const int32_t* aux, const
     hipLaunchKernelGGL(env_import_kernel, dim3(tvc::ceil_div(e->n, 256)), dim3(256), 0, (hipStream_t)stream, e->buf, e->W,
                        dyn, aux, pa, par, hist);
     TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int tvc_env_set_components_out(tvc_env* e, float* comps_dev) {
+    if (!e) return tvc::set_error(TVC_EINVAL, "env is NULL");
+    if (comps_dev && (reinterpret_cast<uintptr_t>(comps_dev) & 15)) return tvc::set_error(TVC_EINVAL, "comps_dev must be 16-byte aligned");
+    e->comps_out = comps_dev;
     return 0;
 }
 

@@ -65,6 +65,9 @@ struct StepOut {
     float obs[10];
     float reward;
     unsigned term, trunc;
+    // reward_components of compute_reward (ref :97-112) + anti-hacking adjustment + unclipped total; only stored when the
+    // caller asked for them (tvc_env_set_components_out)
+    float comps[12];
 };
 
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -411,9 +414,15 @@ __device__ __forceinline__ void epilogue(Regs& r, float (&hw)[12], const DevCfg&
     r.pa0 = a0; r.pa1 = a1; r.has_pa = 1;
     float altm = __expf(-2.0f * fabsf(alt - 3.0f));
     float total = mc * 100.0f + safe * 50.0f + fe * 20.0f + stab * 10.0f + smooth * 5.0f + altm * 5.0f;
-    if (crashed) total += -1000.0f;
-    if (tilt > 0.52f) total += -500.0f * (tilt - 0.52f);
-    if (ce > 0.9f) total += -50.0f * (ce - 0.9f);
+    const float crash_pen = crashed ? -1000.0f : 0.0f;
+    const float tilt_excess = tilt > 0.52f ? -500.0f * (tilt - 0.52f) : 0.0f;
+    const float sat_pen = ce > 0.9f ? -50.0f * (ce - 0.9f) : 0.0f;
+    total += crash_pen;
+    total += tilt_excess;
+    total += sat_pen;
+    out.comps[0] = mc * 100.0f; out.comps[1] = safe * 50.0f; out.comps[2] = fe * 20.0f; out.comps[3] = stab * 10.0f;
+    out.comps[4] = smooth * 5.0f; out.comps[5] = altm * 5.0f;
+    out.comps[6] = crash_pen; out.comps[7] = tilt_excess; out.comps[8] = sat_pen;
 
     // anti-hacking (ref :209-224): variance of the last 10 when len > 10; distinct fraction > 0.8
     const unsigned W = W10 ? 10u : (unsigned)c.W;
@@ -455,6 +464,9 @@ __device__ __forceinline__ void epilogue(Regs& r, float (&hw)[12], const DevCfg&
     // distinct > 0.8 * len  <=>  5 * distinct > 4 * len for len <= 1000 (checked in tests)
     if (5u * r.distinct > 4u * wl) adj += 0.05f;
     total += adj;
+    out.comps[9] = adj; out.comps[10] = total;
+    // presence mask of the penalty keys (the reference's dict only holds the penalties that fired, ref :189-207)
+    out.comps[11] = (float)((crashed ? 1 : 0) | (tilt > 0.52f ? 2 : 0) | (ce > 0.9f ? 4 : 0));
     total = fminf(fmaxf(total, -1000.0f), 200.0f);
 
     // append to the window, maintain the distinct count incrementally

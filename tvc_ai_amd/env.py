@@ -8,6 +8,8 @@
 The arithmetic runs in hand-written HIP kernels (csrc/tvc_env.hip); nothing here computes physics.
 """
 import ctypes as C
+from dataclasses import dataclass
+from enum import Enum
 from typing import Optional
 
 import numpy as np
@@ -16,6 +18,51 @@ import torch
 from . import _native as nat
 
 PHASE_NAMES = ["boost", "coast", "landing", "touchdown", "hover", "complete", "failed"]  # ref :21-29
+
+
+class MissionPhase(Enum):
+    """ref env/enhanced_rocket_tvc_env.py:21-29; member ORDER is the phase index of obs[8] = index / 7 (:593) and of
+    the kernel (tvc_env_device.h: phase_value)."""
+    BOOST = "boost"
+    COAST = "coast"
+    LANDING = "landing"
+    TOUCHDOWN = "touchdown"
+    HOVER = "hover"
+    COMPLETE = "complete"
+    FAILED = "failed"
+
+
+class SuccessCriteria(Enum):
+    """ref env/enhanced_rocket_tvc_env.py:31-37"""
+    ATTITUDE = "attitude"
+    VELOCITY = "velocity"
+    POSITION = "position"
+    STABILITY = "stability"
+    FUEL = "fuel"
+
+
+@dataclass
+class MissionSuccess:
+    """Thresholds of the reference's success detector (ref :39-56).  The kernel hard-codes the same numbers
+    (tvc_env_device.h: epilogue); this object is the read-only surface scripts look at."""
+    max_tilt_angle: float = 0.087
+    max_angular_velocity: float = 0.1
+    max_horizontal_velocity: float = 0.5
+    max_vertical_velocity: float = 2.0
+    min_altitude: float = 0.2
+    max_altitude: float = 2.0
+    position_tolerance: float = 1.0
+    success_duration: int = 100
+    boost_duration: int = 100
+    coast_duration: int = 200
+    landing_duration: int = 300
+    touchdown_duration: int = 100
+
+
+# key order of info['reward_components'] (MultiObjectiveReward.compute_reward, ref :97-112, penalties :189-207)
+REWARD_COMPONENT_KEYS = ["mission_completion", "safety_compliance", "fuel_efficiency", "stability_bonus",
+                         "control_smoothness", "altitude_maintenance", "crash_penalty", "excessive_tilt",
+                         "control_saturation"]
 OBS_DIM = 10
 ACT_DIM = 2
 
@@ -51,6 +98,9 @@ class Box:
 
     def seed(self, seed=None):
         self._rng = np.random.default_rng(seed)
+
+    def __repr__(self):
+        return f"Box({self.low.min()}, {self.high.max()}, {self.shape}, {self.dtype})"
 
 
 def _spaces():
@@ -136,6 +186,7 @@ class VecRocketTVCEnv:
         self.term = torch.empty((n,), dtype=torch.uint8, device=self.device)
         self.trunc = torch.empty((n,), dtype=torch.uint8, device=self.device)
         self.final_obs = torch.empty((n, OBS_DIM), dtype=torch.float32, device=self.device) if want_final_obs else None
+        self.reward_components = None
         self.observation_space, self.action_space = _spaces()
 
     # -- lifecycle
@@ -174,6 +225,17 @@ class VecRocketTVCEnv:
                                       self._stream()))
         info = {"final_observation": self.final_obs} if self.final_obs is not None else {}
         return obs, self.rew, self.term, self.trunc, info
+
+    def enable_reward_components(self, on: bool = True):
+        """Every following step() also fills ``self.reward_components`` [N,12]: the nine reward_components of the reference
+        (ref :97-112, key order REWARD_COMPONENT_KEYS; a penalty that did not fire is 0), the anti-hacking adjustment, the
+        unclipped total and the penalty presence mask."""
+        if on and self.reward_components is None:
+            self.reward_components = torch.zeros((self.num_envs, 12), dtype=torch.float32, device=self.device)
+        if not on:
+            self.reward_components = None
+        nat.check(self.L.tvc_env_set_components_out(self._h, nat.ptr(self.reward_components)))
+        return self.reward_components
 
     @staticmethod
     def observation_view(obs: torch.Tensor, mode: int = 10) -> torch.Tensor:
@@ -273,7 +335,11 @@ class EnhancedRocketTVCEnv:
         # reference semantics: whole-history distinct window, no auto-reset, no DR
         self._vec = VecRocketTVCEnv(1, device=device, config=self.config, max_episode_steps=max_episode_steps,
                                     auto_reset=0, distinct_window=1000)
+        self._vec.enable_reward_components()
         self.observation_space, self.action_space = _spaces()
+        self.mission_success = MissionSuccess()
+        self.current_phase = MissionPhase.BOOST
+        self.mission_successful = False
         self.current_step = 0
         self._act = torch.zeros((1, ACT_DIM), dtype=torch.float32, device=self._vec.device)
         self._curiosity = None
@@ -304,6 +370,8 @@ class EnhancedRocketTVCEnv:
             self.action_space.seed(seed)
         obs, _ = self._vec.reset()
         self.current_step = 0
+        self.current_phase = MissionPhase.BOOST
+        self.mission_successful = False
         self._prev_obs8 = None
         return obs[0].cpu().numpy().copy(), self._info()
 
@@ -313,16 +381,25 @@ class EnhancedRocketTVCEnv:
         obs, rew, term, trunc, _ = self._vec.step(self._act)
         self.current_step += 1
         reward = float(rew[0].item())
+        comps = self._vec.reward_components[0].cpu().numpy()
+        present = int(comps[11])
+        reward_components = {k: float(comps[i]) for i, k in enumerate(REWARD_COMPONENT_KEYS)
+                             if i < 6 or (present >> (i - 6)) & 1}  # the dict only holds penalties that fired (ref :189-207)
         if self._curiosity is not None:
             if self._prev_obs8 is not None:  # skipped on the first step of an episode (ref :496)
-                reward += float(self._curiosity.intrinsic_reward(self._prev_obs8, self._act, obs[:, :8])[0].item())
+                intrinsic = float(self._curiosity.intrinsic_reward(self._prev_obs8, self._act, obs[:, :8])[0].item())
+                reward += intrinsic
+                reward_components["curiosity"] = intrinsic
             self._prev_obs8 = obs[:, :8].clone()
         obs_np = obs[0].cpu().numpy().copy()
         terminated, truncated = bool(term[0].item()), bool(trunc[0].item())
         info = self._info()
         aux = self._vec.export_state()["aux"][0].cpu().numpy()
-        info["mission_successful"] = bool(aux[2])
-        info["mission_phase"] = PHASE_NAMES[int(aux[1])]
+        self.mission_successful = bool(aux[2])
+        self.current_phase = list(MissionPhase)[int(aux[1])]
+        info["reward_components"] = reward_components  # ref :514-516
+        info["mission_phase"] = self.current_phase.value
+        info["mission_successful"] = self.mission_successful
         return obs_np, reward, terminated, truncated, info
 
     def render(self, mode: str = "human"):
@@ -337,14 +414,17 @@ def make_enhanced_tvc_env(**kwargs) -> EnhancedRocketTVCEnv:
     return EnhancedRocketTVCEnv(**kwargs)
 
 
-# ref: env/__init__.py:28-102 factories
+# ref: env/__init__.py:66-102 factories (same default keyword sets)
 def make_training_env(config=None, **kw):
-    return EnhancedRocketTVCEnv(config=config, **{"enable_curiosity": True, **kw})
+    return EnhancedRocketTVCEnv(config=config, **{"max_episode_steps": 1000, "enable_hierarchical": True, "enable_curiosity": True,
+                                                  "enable_physics_informed": True, "debug": False, **kw})
 
 
 def make_evaluation_env(config=None, **kw):
-    return EnhancedRocketTVCEnv(config=config, **{"enable_curiosity": False, **kw})
+    return EnhancedRocketTVCEnv(config=config, **{"max_episode_steps": 1000, "enable_hierarchical": False, "enable_curiosity": False,
+                                                  "enable_physics_informed": False, "debug": False, **kw})
 
 
 def make_debug_env(config=None, **kw):
-    return EnhancedRocketTVCEnv(config=config, **{"debug": True, **kw})
+    return EnhancedRocketTVCEnv(config=config, **{"render_mode": "human", "max_episode_steps": 1000, "enable_hierarchical": True,
+                                                  "enable_curiosity": True, "enable_physics_informed": True, "debug": True, **kw})
