@@ -139,6 +139,13 @@ int tvc_env_import_state(tvc_env* env, const float* dyn_dev, const int32_t* aux_
  * NULL (default) switches it off.  The pointer is caller-owned device memory that must outlive the steps. */
 int tvc_env_set_components_out(tvc_env* env, float* comps_dev);
 
+/* On-device episode statistics: what StateOfTheArtTrainer keeps per episode on the host (scripts/train.py:594-616: episode
+ * reward, length, success) and feeds to the curriculum manager (:458-460), accumulated by the step kernel so that N envs need no
+ * host round trip.  ep_return_dev float[N] (running extrinsic return of each env's current episode, zero it before use);
+ * sums_dev double[64]: [0] episodes finished, [16] of which mission_successful, [32] sum of their returns, [48] sum of their
+ * lengths (one 128-byte line each; the caller zeroes / reads them).  NULL, NULL switches it off (default). */
+int tvc_env_set_episode_stats(tvc_env* env, float* ep_return_dev, double* sums_dev);
+
 /* info dict of _get_enhanced_info (env/...:723-742) as tensors:
  *   info_dev float[N,8]: x, y, altitude, tilt_angle_deg, angular_velocity_mag, fuel, phase idx,
  *                        success_criteria_met(last 10) */
@@ -312,6 +319,7 @@ typedef struct tvc_replay tvc_replay;
  * SURVEY a21; legacy surface: store_transition / len(replay_buffer), tests/test_agent.py:99-108).
  * Row = {s[obs], a[A], r, s2[obs], d} stored row-major ("array of rows": a sampled batch is 256 random
  * 96-byte rows, each one contiguous). */
+/* The buffer starts zero-filled: sampling before the first insert returns all-zero transitions, not uninitialised memory. */
 int tvc_replay_create(int64_t capacity, int32_t obs_dim, int32_t act_dim, int32_t device, tvc_replay** out);
 void tvc_replay_destroy(tvc_replay* rb);
 int64_t tvc_replay_size(const tvc_replay* rb);

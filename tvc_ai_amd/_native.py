@@ -53,6 +53,7 @@ SIGNATURES = {
     "tvc_env_import_state": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "tvc_env_info": (C.c_int, [_VP, _VP, _VP]),
     "tvc_env_set_components_out": (C.c_int, [_VP, _VP]),
+    "tvc_env_set_episode_stats": (C.c_int, [_VP, _VP, _VP]),
     "tvc_debug_hwid": (C.c_int, [_VP, C.c_int32, _VP]),
     "tvc_debug_philox": (C.c_int, [_VP, _VP, C.c_int32, _VP]),
     "tvc_env_fuel_thresholds": (C.c_int, [_VP, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -46,7 +46,7 @@ template <bool W10, bool DR>
 __global__ void __launch_bounds__(kMaxBlock)
 env_step_kernel(EnvBuf b, DevCfg c, DrCfg d, const float* __restrict__ act, float* __restrict__ obs,
                 float* __restrict__ rew, unsigned char* __restrict__ term, unsigned char* __restrict__ trunc,
-                float* __restrict__ final_obs, float* __restrict__ comps, int n_steps) {
+                float* __restrict__ final_obs, float* __restrict__ comps, EpStats ep, int n_steps) {
     __shared__ __attribute__((aligned(16))) float tile[kMaxBlock * 10];
     const int row0 = blockIdx.x * blockDim.x;
     const int i = row0 + threadIdx.x;
@@ -80,6 +80,25 @@ env_step_kernel(EnvBuf b, DevCfg c, DrCfg d, const float* __restrict__ act, floa
                 cp[1] = make_float4(o.comps[4], o.comps[5], o.comps[6], o.comps[7]);
                 cp[2] = make_float4(o.comps[8], o.comps[9], o.comps[10], o.comps[11]);
             }
+        }
+        if (ep.ret != nullptr) {  // uniform branch: episode statistics, one atomic set per wavefront that saw an episode end
+            float R = 0.0f;
+            if (valid) R = ep.ret[i] + o.reward;
+            const bool fin = valid && done;
+            if (__any(fin)) {
+                float c = fin ? 1.0f : 0.0f, sc = (fin && r.msucc) ? 1.0f : 0.0f, rs = fin ? R : 0.0f, ls = fin ? (float)r.step : 0.0f;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    c += __shfl_xor(c, m); sc += __shfl_xor(sc, m); rs += __shfl_xor(rs, m); ls += __shfl_xor(ls, m);
+                }
+                if ((threadIdx.x & 63) == 0) {
+                    atomicAdd(ep.sums, (double)c);
+                    if (sc > 0.0f) atomicAdd(ep.sums + 16, (double)sc);
+                    atomicAdd(ep.sums + 32, (double)rs);
+                    atomicAdd(ep.sums + 48, (double)ls);
+                }
+            }
+            if (valid) ep.ret[i] = fin ? 0.0f : R;
         }
         if (final_obs != nullptr) {
             __syncthreads();
@@ -264,6 +283,7 @@ struct tvc_env {
     int W;
     void* slab;
     float* comps_out;  // optional [N,12] reward-component sink (tvc_env_set_components_out)
+    EpStats ep;        // optional episode statistics (tvc_env_set_episode_stats)
 };
 
 static int fuel_threshold(double thr, bool strict_less) {
@@ -351,6 +371,7 @@ int tvc_env_create(const tvc_env_cfg* cfg, int32_t n_envs, int32_t device, tvc_e
     tvc_env* e = new (std::nothrow) tvc_env();
     if (!e) return tvc::set_error(TVC_ENOMEM, "host allocation failed");
     e->cfg = *cfg; e->n = n_envs; e->device = device; e->W = cfg->distinct_window; e->comps_out = nullptr;
+    e->ep.ret = nullptr; e->ep.sums = nullptr;
     build_devcfg(*cfg, e->W, e->dc, e->dr);
     const int np = tvc::ceil_div(n_envs, 64) * 64;
     const size_t bytes = (size_t)np * kCellGroups * sizeof(float4) + (e->W == 1000 ? (size_t)np * 1000 * sizeof(float) : 0);
@@ -428,7 +449,7 @@ static int launch_step(tvc_env* e, int n_steps, const float* act, float* obs, fl
     hipStream_t st = (hipStream_t)stream;
 #define TVC_LAUNCH_STEP(A, B)                                                                                         \
     hipLaunchKernelGGL((env_step_kernel<A, B>), grid, block, 0, st, e->buf, e->dc, e->dr, act, obs, rew, term, trunc, \
-                       final_obs, n_steps == 1 ? e->comps_out : nullptr, n_steps)
+                       final_obs, n_steps == 1 ? e->comps_out : nullptr, e->ep, n_steps)
     if (w10 && !dr) TVC_LAUNCH_STEP(true, false);
     else if (w10 && dr) TVC_LAUNCH_STEP(true, true);
     else if (!w10 && !dr) TVC_LAUNCH_STEP(false, false);
@@ -471,6 +492,14 @@ int tvc_env_set_components_out(tvc_env* e, float* comps_dev) {
     if (!e) return tvc::set_error(TVC_EINVAL, "env is NULL");
     if (comps_dev && (reinterpret_cast<uintptr_t>(comps_dev) & 15)) return tvc::set_error(TVC_EINVAL, "comps_dev must be 16-byte aligned");
     e->comps_out = comps_dev;
+    return 0;
+}
+
+int tvc_env_set_episode_stats(tvc_env* e, float* ep_return_dev, double* sums_dev) {
+    if (!e) return tvc::set_error(TVC_EINVAL, "env is NULL");
+    if ((ep_return_dev == nullptr) != (sums_dev == nullptr)) return tvc::set_error(TVC_EINVAL, "pass both buffers or neither");
+    e->ep.ret = ep_return_dev;
+    e->ep.sums = sums_dev;
     return 0;
 }
 

@@ -52,6 +52,14 @@ struct EnvBuf {
     int n, np;
 };
 
+// Optional on-device episode statistics (curriculum driver / logging without host round trips):
+// ret[N] = running extrinsic return of the current episode; sums = {episodes, successes, return sum, length sum}, each on its
+// own 128-byte line (sums[16 * k]).
+struct EpStats {
+    float* ret;
+    double* sums;
+};
+
 struct Regs {
     float px, py, pz, qx, qy, qz, qw, vx, vy, vz, wx, wy, wz;
     float pa0, pa1;

@@ -100,7 +100,14 @@ int tvc_replay_create(int64_t capacity, int32_t obs_dim, int32_t act_dim, int32_
         return tvc::set_error(TVC_ENOMEM, "hipMalloc(%ld) failed: %s", bytes, hipGetErrorString(he));
     }
     rb->st = (long*)((char*)rb->buf + bytes);
-    (void)hipMemset(rb->st, 0, 64);
+    // rows AND counters start at zero: a sample drawn before the first insert gathers row 0 = an all-zero transition
+    // (finite), never uninitialised memory
+    he = hipMemset(rb->buf, 0, bytes + 64);
+    if (he != hipSuccess) {
+        (void)hipFree(rb->buf);
+        delete rb;
+        return tvc::set_error(TVC_EHIP, "hipMemset failed: %s", hipGetErrorString(he));
+    }
     *out = rb;
     return 0;
 }

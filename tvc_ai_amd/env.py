@@ -135,6 +135,21 @@ def make_cfg(config: Optional[dict] = None, max_episode_steps: int = 1000, **ove
     return cfg
 
 
+STAGE_EPISODES = [0, 200, 300, 400, 500, 600]  # config/config.yaml:240-281 (`episodes:` of each stage; 0 = the build's nominal stage)
+
+
+def default_curriculum_config() -> dict:
+    """The `curriculum:` section of the shipped config/config.yaml:226-286 rebuilt from CURRICULUM_STAGES (stages 1-5), in the
+    shape scripts/curriculum_manager.py:60-95 (and curriculum.CurriculumDriver) parses."""
+    stages = {}
+    for i, st in enumerate(CURRICULUM_STAGES[1:], start=1):
+        stages[f"stage_{i}"] = {"name": st["name"], "episodes": STAGE_EPISODES[i],
+                                "environment": {"wind_force": st["wind_force"], "mass_variation": st["mass_variation"],
+                                                "initial_tilt_max": st["initial_tilt_max"],
+                                                "success_threshold": st["success_threshold"]}}
+    return {"enabled": True, "type": "adaptive", "stages": stages}
+
+
 def dr_from_yaml(config: dict, stage: Optional[int] = None) -> dict:
     """Domain-randomisation ranges from config/config.yaml:340-349, optionally narrowed to a
     curriculum stage (config.yaml:236-286)."""
@@ -225,6 +240,25 @@ class VecRocketTVCEnv:
                                       self._stream()))
         info = {"final_observation": self.final_obs} if self.final_obs is not None else {}
         return obs, self.rew, self.term, self.trunc, info
+
+    def enable_episode_stats(self, on: bool = True):
+        """The step kernel accumulates per-episode return / length / success on the device (tvc_env_set_episode_stats):
+        what scripts/train.py:594-616 keeps per episode on the host.  Read with episode_stats()."""
+        if on:
+            self._ep_ret = torch.zeros((self.num_envs,), dtype=torch.float32, device=self.device)
+            self._ep_sums = torch.zeros((64,), dtype=torch.float64, device=self.device)
+            nat.check(self.L.tvc_env_set_episode_stats(self._h, self._ep_ret.data_ptr(), self._ep_sums.data_ptr()))
+        else:
+            nat.check(self.L.tvc_env_set_episode_stats(self._h, None, None))
+            self._ep_ret = self._ep_sums = None
+
+    def episode_stats_tensor(self):
+        """device view [4] = episodes finished, successes, return sum, length sum (running totals since enable)"""
+        return self._ep_sums[::16]
+
+    def episode_stats(self) -> dict:
+        e, s, r, l = self.episode_stats_tensor().cpu().tolist()  # synchronises
+        return {"episodes": int(e), "successes": int(s), "return_sum": r, "length_sum": l}
 
     def enable_reward_components(self, on: bool = True):
         """Every following step() also fills ``self.reward_components`` [N,12]: the nine reward_components of the reference

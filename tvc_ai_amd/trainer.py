@@ -69,6 +69,7 @@ class VecTrainer:
                          torch.empty((B, 10), device=d), torch.empty((B,), device=d)) for _ in range(K)]
         self.batch = self.batches[0]
         self._snapshot = False  # collect() acts with the policy snapshot (overlapped schedule)
+        self.curriculum = None
         self.prev_done = torch.ones((n,), dtype=torch.uint8, device=d)  # 1 = next step is the first of an episode
         torch.manual_seed(seed + rank)  # default CUDA generator: hipGraph-capturable normal draws
         o, _ = self.env.reset()
@@ -85,6 +86,42 @@ class VecTrainer:
             self.hier.close()
         if self.safety is not None:
             self.safety.close()
+
+    # -- curriculum (scripts/train.py:458-460 calls the manager once per episode on the host and drops its answer, SURVEY
+    #    F11; here the driver reads device-side episode statistics every `every` vector steps WITHOUT stalling the loop: the
+    #    counters are copied to pinned memory behind an event and consumed one period later)
+    def attach_curriculum(self, driver, every: int = 100, min_episodes: int = 50):
+        self.curriculum = driver
+        driver.env = self.env
+        driver._apply()
+        self._cur_every, self._cur_min_eps = int(every), int(min_episodes)
+        self.env.enable_episode_stats()
+        self._cur_host = torch.zeros(4, dtype=torch.float64).pin_memory()
+        self._cur_event = torch.cuda.Event()
+        self._cur_pending = False
+        self._cur_last = [0.0, 0.0, 0.0, 0.0]
+        self.curriculum_log = []
+
+    def _curriculum_tick(self):
+        if self._cur_pending and self._cur_event.query():
+            tot = self._cur_host.tolist()
+            d = [a - b for a, b in zip(tot, self._cur_last)]
+            if d[0] >= self._cur_min_eps:  # enough finished episodes for an evaluation (the reference evaluates 50, :success_criteria)
+                self._cur_last = tot
+                metrics = {"eval_success_rate": d[1] / d[0], "eval_reward_mean": d[2] / d[0], "eval_length_mean": d[3] / d[0]}
+                before = self.curriculum.current_stage_idx
+                self.curriculum.update(self.steps * self.n * self.world, metrics)
+                self.curriculum_log.append({"step": self.steps, "episodes": d[0], **metrics, "stage_before": before,
+                                            "stage_after": self.curriculum.current_stage_idx})
+            self._cur_pending = False
+        if not self._cur_pending and self.steps % self._cur_every == 0:
+            tot = self.env.episode_stats_tensor().clone()
+            if self.world > 1:  # every rank's driver sees the whole job's episodes, so all ranks change stage together
+                import torch.distributed as dist
+                dist.all_reduce(tot)
+            self._cur_host.copy_(tot, non_blocking=True)
+            self._cur_event.record()
+            self._cur_pending = True
 
     def collect(self):
         """act + env step + replay insert"""
@@ -123,6 +160,8 @@ class VecTrainer:
                 for k in range(self.updates_per_step):
                     self.learn(k)
         self.steps += 1
+        if self.curriculum is not None:
+            self._curriculum_tick()
 
     def _step_overlapped(self):
         """Same work as collect() + updates_per_step x learn(), on two HIP streams.  The acting pass (large GEMMs over
