@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s (+ SAC updates/s) of the MI355X-native rocket-TVC hot path.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched by torch.distributed.run, one
-rank per GPU).  W untimed warm-up steps, then exactly K timed steps between barrier +
-torch.cuda.synchronize() on both sides, MAX over ranks, rank 0 prints ONE JSON line.
+Contract: `python bench.py --gpus N --steps K --warmup W`.  N>1: one rank per GPU over RCCL, either launched by
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) or -- when started directly without WORLD_SIZE --
+bench.py launches its own N ranks as a child `python -m torch.distributed.run` BEFORE anything in this process touches the
+GPU, relays rank 0's JSON line and exits with the children's code.  It exits non-zero when the ranks that joined differ from
+--gpus.  W untimed warm-up steps, then exactly K timed steps between barrier + torch.cuda.synchronize() on both sides, MAX
+over ranks, rank 0 prints ONE JSON line.
 
 A "step" is one pass of the hot path over one batch of synthetic input:
   workload "physics" : one vector env step (N_env envs/GPU, pre-generated U(-1,1)^2 actions, auto-reset)
   workload "train"   : policy act on N_env observations -> vector env step -> replay insert ->
                        one SAC update at batch 256 (available once the learner kernels are built)
 Envs shard over ranks with no data-path collective in "physics"; "train" adds the critic/actor gradient
-all-reduce (RCCL) of the update.  scaling = weak (envs per GPU fixed).
+all-reduce (RCCL) of the update.  Default scaling = weak (--envs-per-gpu fixed, 65 536 = the metric's "64k parallel envs" on
+every GPU); `--total-envs T` fixes the job size instead (strong scaling: T / N envs per GPU, e.g. 65 536 -> 8 192 per GPU at
+N = 8 = BASELINE configs[4]).  With N > 1 the weak line also carries a `strong_scaling` object measured in the same run.
+The default train workload is BASELINE configs[4]'s environment: full domain randomisation at curriculum stage 5 with the
+curriculum driver attached (`--dr-stage 0` = the shipped, un-randomised env).
 """
 import argparse
 import json
@@ -31,6 +38,9 @@ MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak (= fp
 # writes dyn 13 + prev_action 2 + aux 2 + episode 1 + window slot 1 + obs 10 + reward 1  = 30 words + 2 flag bytes
 # (the 16-byte-cell layout actually moves 136 B in + 142 B out = 278 B; PMC-confirmed, profiles/r01_b_*)
 ENV_STEP_BYTES = 30 * 4 + 30 * 4 + 2
+# domain-randomised instantiation: + the six per-episode parameters (mass / thrust scale, cg offset, wind xyz) READ each step
+# (they only change at a reset, so their write-back is not algorithmic); + 8 B when the episode statistics are on (running return)
+ENV_STEP_BYTES_DR = ENV_STEP_BYTES + 6 * 4
 
 
 def parse():
@@ -43,7 +53,10 @@ def parse():
                          "8192 = the per-GPU shard of configs[4] (65 536 envs on 8 GPUs)")
     ap.add_argument("--workload", choices=["physics", "train", "auto"], default="auto")
     ap.add_argument("--family", type=int, default=0, help="SAC network family: 0 = reference shapes, 1 = 256x256 MLP")
-    ap.add_argument("--dr-stage", type=int, default=None, help="train: domain randomisation at curriculum stage 0-5 (default: off)")
+    ap.add_argument("--total-envs", type=int, default=0, help="strong scaling: total envs of the job, split evenly over the ranks "
+                                                              "(overrides --envs-per-gpu; 65536 = BASELINE configs[4])")
+    ap.add_argument("--dr-stage", type=int, default=5, help="train: domain randomisation at curriculum stage 0-5 (config.yaml:236-286, "
+                                                            "340-349) with the curriculum driver attached; 0 = shipped env, no DR")
     ap.add_argument("--updates-per-step", type=int, default=1, help="train: SAC updates per vector step (they run beside the "
                                                                       "acting pass on the second stream)")
     ap.add_argument("--shipped-acting", action="store_true", help="train: act like the reference under its shipped config.yaml "
@@ -57,6 +70,29 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample length (0 = skip)")
     ap.add_argument("--roofline-envs", type=int, default=1 << 22, help="bandwidth-regime size for the extra roofline point")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start N ranks as a child torch.distributed.run.  Nothing in this process has touched
+    the GPU (importing torch and counting devices does not initialise HIP on this image) and nothing will: it only waits."""
+    import socket
+    import subprocess
+    forced = os.environ.get("TVC_FORCE_DEVICE") is not None  # rehearsal on a 1-GPU box: all ranks on one card over gloo
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and not forced:
+        print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible; refusing to run fewer ranks than asked "
+              f"(set TVC_FORCE_DEVICE=0 TVC_DIST_BACKEND=gloo to rehearse on one card)", file=sys.stderr)
+        return 2
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["TVC_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
 
 
 def dist_setup(args):
@@ -79,8 +115,13 @@ def dist_setup(args):
     else:
         torch.cuda.set_device(0)
         local = 0
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if args.gpus != world:  # never report a line for a job other than the one asked for
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but {world} rank(s) joined (WORLD_SIZE={world}); aborting", file=sys.stderr)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        sys.exit(3)
     return world, rank, local
 
 
@@ -186,32 +227,101 @@ def cpu_baseline(seconds, n_envs=0):
     return out
 
 
+def timed_steps(step_fn, K, W, world, device, use_graph):
+    """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides; max over ranks.
+    -> (seconds, device microseconds per step from HIP events on the launch stream, captured?)"""
+    for k in range(W):
+        step_fn(k)
+    torch.cuda.synchronize(device)
+    graph = None
+    if use_graph:
+        try:
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(device)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    for k in range(K):
+                        step_fn(k)
+            torch.cuda.current_stream(device).wait_stream(side)
+            torch.cuda.synchronize(device)
+        except Exception as e:  # e.g. a collective that cannot be captured: fall back to eager launches
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize(device)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier(world)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    ev0.record()  # HIP events on the stream the kernels are launched on (torch's current stream)
+    if graph is not None:
+        graph.replay()
+    else:
+        for k in range(K):
+            step_fn(k)
+    ev1.record()
+    torch.cuda.synchronize(device)
+    barrier(world)
+    dt = time.perf_counter() - t0
+    dt = max_over_ranks(dt, world, device)
+    return dt, ev0.elapsed_time(ev1) * 1e3 / K, graph is not None
+
+
+def allreduce_report(tr, world, device):
+    """What the data-parallel update exchanges, and how long the two collectives take on their own (measured here,
+    back to back on the gradient buffers themselves, max over ranks)."""
+    sac = tr.sac
+    sizes = [int((sac.grads.numel() - sac.n_policy) * 4), int(sac.n_policy * 4)]
+    rep = {"calls_per_update": 2, "bytes_per_update": sum(sizes), "critic_bytes": sizes[0], "actor_bytes": sizes[1],
+           "op": "all_reduce(sum) over the flat fp32 gradient slices; 1/world folded into the Adam kernel"}
+    if world == 1:
+        rep["measured_us_per_update"] = None
+        rep["note"] = "single rank: no collective is issued"
+        return rep
+    import torch.distributed as dist
+    bufs = [torch.zeros_like(sac.grads[sac.n_policy:]), torch.zeros_like(sac.grads[:sac.n_policy])]
+    for _ in range(5):
+        for b in bufs:
+            dist.all_reduce(b)
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    reps = 50
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for b in bufs:
+            dist.all_reduce(b)
+    torch.cuda.synchronize(device)
+    us = max_over_ranks((time.perf_counter() - t0) / reps * 1e6, world, device)
+    rep["measured_us_per_update"] = us
+    rep["bus_gbps"] = 2.0 * (world - 1) / world * sum(sizes) / (us * 1e-6) / 1e9
+    rep["calls_counted_in_timed_region"] = tr.sync.calls if tr.sync is not None else 0
+    return rep
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     world, rank, local = dist_setup(args)
     device = torch.device("cuda", local)
     from tvc_ai_amd import VecRocketTVCEnv
     workload = args.workload
-    have_agent = False
     if workload in ("auto", "train"):
-        try:
-            from tvc_ai_amd import trainer as _trainer  # noqa: F401
-            have_agent = True
-        except ImportError:
-            have_agent = False
-        if workload == "train" and not have_agent:
-            raise SystemExit("workload 'train' needs tvc_ai_amd.trainer")
-        workload = "train" if have_agent else "physics"
+        from tvc_ai_amd import trainer  # noqa: F401  (fails loudly: the HIP library is the product)
+        workload = "train"
 
-    n = args.envs_per_gpu
+    strong = args.total_envs > 0
+    if strong and args.total_envs % world:
+        raise SystemExit(f"--total-envs {args.total_envs} does not divide over {world} ranks")
+    n = args.total_envs // world if strong else args.envs_per_gpu
     K, W = args.steps, args.warmup
+    backend = (os.environ.get("TVC_DIST_BACKEND", "nccl") if world > 1 else None)
     extra = {}
+    tr = None
     if workload == "train":
-        from tvc_ai_amd import trainer
-        result = trainer.bench_train(args, world, rank, device)
-        step_fn, sync_extra = result["step_fn"], result
+        result = trainer.bench_train(args, world, rank, device, n_envs=n)
+        step_fn, tr = result["step_fn"], result["trainer"]
         extra.update(result.get("extra", {}))
-        env = result["env"]
     else:
         env = VecRocketTVCEnv(n, device=device, seed=42, env_id_offset=rank * n)
         env.reset()
@@ -235,51 +345,17 @@ def main():
             def step_fn(k):
                 env.step(acts[k % n_act])
 
-    for k in range(W):
-        step_fn(k)
-    torch.cuda.synchronize(device)
-
-    graph = None
     # physics: one kernel per step -> capture the K launches in one hipGraph (removes the per-launch host cost).
     # train: ~140 launches per step; eager keeps the graph size independent of K (a 1000-step graph would hold 140k
-    # nodes) and measures the same as a captured loop because the host stays ahead of the device
-    use_graph = (not args.no_graph) and (workload == "physics" or (args.graph and world == 1))
+    # nodes) and measures the same as a captured loop because the host stays ahead of the device.
     # multi-GPU train: the two gradient all-reduces (RCCL) sit between kernel phases; they are issued eagerly
     # rather than captured (collective capture is not something a 1-GPU gpurun box can validate)
-    if use_graph:
-        try:
-            graph = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream(device)
-            side.wait_stream(torch.cuda.current_stream(device))
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(graph, stream=side):
-                    for k in range(K):
-                        step_fn(k)
-            torch.cuda.current_stream(device).wait_stream(side)
-            torch.cuda.synchronize(device)
-        except Exception as e:  # e.g. a collective that cannot be captured: fall back to eager launches
-            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize(device)
-
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    barrier(world)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    ev0.record()  # HIP events on the stream the kernels are launched on (torch's current stream)
-    if graph is not None:
-        graph.replay()
-    else:
-        for k in range(K):
-            step_fn(k)
-    ev1.record()
-    torch.cuda.synchronize(device)
-    barrier(world)
-    dt = time.perf_counter() - t0
-    dt = max_over_ranks(dt, world, device)
-    dev_us_per_step = ev0.elapsed_time(ev1) * 1e3 / K
+    use_graph = (not args.no_graph) and (workload == "physics" or (args.graph and world == 1))
+    dt, dev_us_per_step, captured = timed_steps(step_fn, K, W, world, device, use_graph)
 
     env_steps = float(n) * world * K
+    mode = (f"strong scaling: {args.total_envs} envs in total = {n} per GPU" if strong
+            else f"weak scaling: {n} envs per GPU (the metric's 64k parallel envs on every GPU)")
     out = {
         "metric": "env-steps/sec + SAC updates/sec at 64k parallel envs, 1/2/4/8 MI355X",
         "value": env_steps / dt,
@@ -289,25 +365,46 @@ def main():
         "warmup": W,
         "ms_per_step": dt / K * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": f"{workload}: {n} envs/GPU x {world} GPU(s) = {n * world} envs "
-                               f"(64k parallel envs per GPU, weak scaling), contact + auto-reset, "
-                               f"{'hipGraph of K steps' if graph is not None else 'eager launches'}",
+        "world_size": world,
+        "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else "none (single rank)",
+        "config": {"workload": f"{workload}: {n} envs/GPU x {world} GPU(s) = {n * world} envs ({mode}), contact + auto-reset, "
+                               f"{'hipGraph of K steps' if captured else 'eager launches'}",
                    "envs_per_gpu": n, "total_envs": n * world},
     }
     if workload == "train":
         out["sac_updates_per_s"] = extra.pop("updates_per_step", 1.0) * K * 1.0 / dt
+        out["allreduce"] = allreduce_report(tr, world, device)
+        if tr.curriculum is not None:
+            extra["curriculum"] = {"stage_index": tr.curriculum.current_stage_idx,
+                                   "stage": getattr(tr.curriculum.get_current_stage(), "name", None),
+                                   "evaluations_in_run": len(tr.curriculum_log),
+                                   "last_evaluation": tr.curriculum_log[-1] if tr.curriculum_log else None}
     out.update(extra)
+
+    # weak line at N > 1: also measure the fixed-job-size variant of BASELINE configs[3-4] (65 536 envs over the N GPUs)
+    if workload == "train" and world > 1 and not strong and (n * world) != 65536 and 65536 % world == 0:
+        try:
+            n2 = 65536 // world
+            tr.close()
+            res2 = trainer.bench_train(args, world, rank, device, n_envs=n2)
+            dt2, _, _ = timed_steps(res2["step_fn"], K, W, world, device, False)
+            out["strong_scaling"] = {"total_envs": 65536, "envs_per_gpu": n2, "value": 65536.0 * K / dt2, "unit": "env-steps/s",
+                                     "ms_per_step": dt2 / K * 1e3, "sac_updates_per_s": res2["trainer"].updates_per_step * K / dt2,
+                                     "note": "same run, same K / W, job size fixed at 65 536 envs (BASELINE configs[4])"}
+            tr = res2["trainer"]
+        except Exception as e:
+            out["strong_scaling"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         try:
             out.update(roofline_report(args, workload, n, step_fn if workload == "physics" else None, dev_us_per_step, device))
         except Exception as e:  # the headline line must survive a failure of the diagnostic legs
             out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:  # rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, n if workload == "train" else 0)
             except Exception as e:
@@ -345,31 +442,60 @@ def graph_time_us(fn, reps, device, rounds=5):
     return best
 
 
+PMC_FILE = "profiles/pmc_traffic.json"
+LOOP_STATS_FILE = "profiles/r02_train_loop_kernel_stats.json"
+
+
 def pmc_traffic(n, kernel="env_step_kernel"):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, both in
-    KiB; tools/pmc_to_json.py), keyed by kernel and grid size in threads; None when that size was not profiled."""
+    """HBM bytes per launch from the COMMITTED rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, both in
+    KiB; tools/pmc_to_json.py), keyed by kernel and grid size in threads; None when that size was not profiled.
+    Not measured in this run: the JSON line labels it with `traffic_source`."""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             return json.load(f).get(kernel, {}).get(str(n), {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
 
 
-def integrator_roofline(n, device, us=None):
-    """HBM roofline of env_step_kernel at n envs (fresh env, pre-generated actions)."""
+def in_loop_us(kernel, envs):
+    """rocprofv3 --kernel-trace --stats average of `kernel` INSIDE the train loop (committed summary of this same command,
+    tools/loop_stats_to_json.py), next to the isolated launch time measured live; None when not profiled at this size."""
+    try:
+        with open(os.path.join(ROOT, LOOP_STATS_FILE)) as f:
+            d = json.load(f)
+        return d.get(str(envs), {}).get(kernel)
+    except Exception:
+        return None
+
+
+def integrator_roofline(n, device, us=None, dr_stage=None, stats=False):
+    """HBM roofline of env_step_kernel at n envs (fresh env, pre-generated actions); dr_stage > 0 = the domain-randomised
+    instantiation the default train loop runs."""
     from tvc_ai_amd import VecRocketTVCEnv
+    dr = dr_stage is not None and dr_stage > 0
     if us is None:
-        env = VecRocketTVCEnv(n, device=device, seed=7)
+        over = {}
+        if dr:
+            from tvc_ai_amd.env import dr_from_yaml
+            over = dr_from_yaml({}, dr_stage)
+        env = VecRocketTVCEnv(n, device=device, seed=7, **over)
+        if stats:
+            env.enable_episode_stats()
         env.reset()
         acts = (torch.rand((8, n, 2), device=device) * 2 - 1).contiguous()
         for k in range(40):  # spread the envs over episode phases
             env.step(acts[k % 8])
         us = graph_time_us(lambda k: env.step(acts[k % 8]), 50, device)
         env.close()
-    ach = ENV_STEP_BYTES * n / (us * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": "env_step_kernel<W10,noDR>", "envs": n, "achieved": ach, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(n), "launch_us": us,
-            "algorithmic_bytes_per_launch": ENV_STEP_BYTES * n, "env_steps_per_s": n / (us * 1e-6)}
+    per_env = (ENV_STEP_BYTES_DR if dr else ENV_STEP_BYTES) + (8 if stats else 0)
+    ach = per_env * n / (us * 1e-6) / 1e9
+    kname = "env_step_kernel<W10,DR>" if dr else "env_step_kernel<W10,noDR>"
+    traffic = pmc_traffic(n, "env_step_kernel_dr" if dr else "env_step_kernel")
+    return {"bound": "hbm", "kernel": kname, "envs": n, "achieved": ach, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc pass, not measured in this run)" if traffic else None,
+            "launch_us": us, "algorithmic_bytes_per_env_step": per_env,
+            "algorithmic_bytes_per_launch": per_env * n, "env_steps_per_s": n / (us * 1e-6)}
 
 
 def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device):
@@ -403,13 +529,19 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
                                                                  0, torch.cuda.current_stream(device).cuda_stream), 20, device)
             traffic = pmc_traffic((N // 64) * ((M + 63) // 64) * 256, "tvcnn::gemm_kernel")
         tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
+        loop = in_loop_us(kname.split(" (")[0], n)
         rep["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": tf,
                            "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
-                           "traffic": traffic, "launch_us": us, "flops_per_launch": 2.0 * M * N * K,
-                           "dtype": "f32 in / f32 acc MFMA"}
+                           "traffic": traffic,
+                           "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc pass, not measured in this run)" if traffic else None,
+                           "launch_us": us, "launch_us_source": "live: hipGraph of 20 isolated launches, HIP events on their stream",
+                           "in_loop_us": loop,
+                           "in_loop_source": f"{LOOP_STATS_FILE} (committed rocprofv3 --kernel-trace --stats of the train loop)" if loop else None,
+                           "in_loop_frac": (2.0 * M * N * K / (loop * 1e-6) / 1e12 / MFMA_F32_PEAK_TF) if loop else None,
+                           "flops_per_launch": 2.0 * M * N * K, "dtype": "f32 in / f32 acc MFMA"}
         del R, gam, bet
         del X, W, b, Y
-        rep["roofline_integrator"] = integrator_roofline(n, device)
+        rep["roofline_integrator"] = integrator_roofline(n, device, dr_stage=args.dr_stage, stats=args.dr_stage > 0)
         # learner alone (no env stepping): back-to-back SAC updates at B = 256 on a fixed batch
         try:
             from tvc_ai_amd.agent import NativeSAC, sac_cfg
@@ -488,6 +620,8 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
             rep["reference_plumbing_n1"] = {"error": str(e)}
     try:  # the integrator in its bandwidth regime (H3: small batches are launch/latency-bound)
         rep["roofline_integrator_large_n"] = integrator_roofline(args.roofline_envs, device)
+        if workload == "train" and args.dr_stage > 0:
+            rep["roofline_integrator_large_n_dr"] = integrator_roofline(args.roofline_envs, device, dr_stage=args.dr_stage, stats=True)
     except Exception as e:  # never lose the headline line to the optional point
         rep["roofline_integrator_large_n"] = {"error": str(e)}
     return rep

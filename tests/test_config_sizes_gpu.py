@@ -67,8 +67,8 @@ def test_config4_65536_envs_full_dr_stage5_with_curriculum_driver():
     drv = CurriculumDriver(default_curriculum_config())
     assert [s.name for s in drv.stages] == [s["name"] for s in CURRICULUM_STAGES[1:]]
     drv.current_stage_idx = 3                                   # "advanced_control" = stage 4 of the YAML
-    for st in drv.stages:                                       # make the advancement rule reachable by an untrained policy
-        st.success_criteria = {"min_success_rate": 0.0, "min_avg_reward": -1e9, "evaluation_episodes": 50}
+    # make THIS stage's advancement rule reachable by an untrained policy (the last stage keeps the YAML's 0.9 success rate)
+    drv.stages[3].success_criteria = {"min_success_rate": 0.0, "min_avg_reward": -1e9, "evaluation_episodes": 50}
     drv.current_step = 0
     tr.attach_curriculum(drv, every=10, min_episodes=50)
     assert abs(tr.env.cfg.dr_wind_std - 2.0) < 1e-12 and abs(tr.env.cfg.dr_init_tilt_max - 0.4) < 1e-12

@@ -72,3 +72,18 @@ def test_two_rank_gloo_gradient_sync():
     assert abs(s0 - s1) < 1e-3                        # identical update on every replica
     assert c0 == c1 == 2 and b0 == b1 == 2000 * 4
     assert m0 == m1 == 2.0
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked():
+    """`python bench.py --gpus 8` run directly used to execute on ONE GPU and print n_gpus: 1.  Now a direct
+    `--gpus N` either launches its own N ranks or, when fewer than N GPUs are visible, exits non-zero before touching a GPU."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("an 8-GPU node launches the ranks instead of refusing")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TVC_FORCE_DEVICE")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2, (p.returncode, p.stderr[-500:])
+    assert "refusing to run fewer ranks" in p.stderr and p.stdout.strip() == ""

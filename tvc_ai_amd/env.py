@@ -110,6 +110,10 @@ def _spaces():
     return Box(lo, hi, dtype=np.float32), Box(-1.0, 1.0, shape=(ACT_DIM,), dtype=np.float32)
 
 
+# keys of the YAML's `tvc_native:` section that belong to agent.MultiAlgorithmAgent, not to the env
+AGENT_NATIVE_KEYS = ("batch_size", "max_act_rows", "family", "pe_rows", "dropout", "acting_dropout")
+
+
 def make_cfg(config: Optional[dict] = None, max_episode_steps: int = 1000, **over) -> nat.EnvCfg:
     """tvc_env_cfg from the reference YAML dict (keys under ``env:``) plus explicit overrides."""
     L = nat.load()
@@ -118,6 +122,7 @@ def make_cfg(config: Optional[dict] = None, max_episode_steps: int = 1000, **ove
     cfg.max_episode_steps = int(max_episode_steps)
     config = config or {}
     native = config.get("tvc_native", {}) if isinstance(config, dict) else {}
+    native = {k: v for k, v in (native or {}).items() if k not in AGENT_NATIVE_KEYS}  # the section is shared with the agent
     for k, v in {**native, **over}.items():
         if k in ("init_pos", "init_quat"):
             arr = getattr(cfg, k)

@@ -238,19 +238,28 @@ class VecTrainer:
                 "losses": self.sac.losses.cpu().tolist()}
 
 
-def bench_train(args, world, rank, device):
-    """bench.py workload 'train': returns the step function and the env (for the roofline leg)."""
+def bench_train(args, world, rank, device, n_envs=None):
+    """bench.py workload 'train': returns the step function, the trainer and the description of what runs."""
     family = getattr(args, "family", 0)
+    n = int(n_envs if n_envs is not None else args.envs_per_gpu)
     env_over = {}
     stage = getattr(args, "dr_stage", None)
+    stage = None if stage is None or stage <= 0 else int(stage)
     if stage is not None:  # BASELINE configs[4]: full domain randomisation at a curriculum stage (config.yaml:236-286, 340-349)
         from .env import dr_from_yaml
         env_over = dr_from_yaml({}, stage)
     shipped = bool(getattr(args, "shipped_acting", False))
     utd = max(1, int(getattr(args, "updates_per_step", 1)))
-    tr = VecTrainer(args.envs_per_gpu, device=device, family=family, batch_size=256, replay_capacity=1_000_000, seed=42,
+    tr = VecTrainer(n, device=device, family=family, batch_size=256, replay_capacity=1_000_000, seed=42,
                     rank=rank, world=world, updates_per_step=utd, overlap=not getattr(args, "no_overlap", False),
                     enable_hierarchical=shipped, enable_safety=shipped, enable_curiosity=shipped, **env_over)
+    if stage is not None:  # the curriculum driver reads device-side episode statistics and owns the stage from here on
+        from .curriculum import CurriculumDriver
+        from .env import default_curriculum_config
+        drv = CurriculumDriver(default_curriculum_config())
+        drv.current_stage_idx = stage - 1
+        drv.current_step = sum(s.duration_steps for s in drv.stages[:stage - 1])
+        tr.attach_curriculum(drv, every=50, min_episodes=50)
     fam = "reference shapes (seq-len-1 transformer actor 2.26M trainable params, 512/256 GELU+LN critics)" if family == 0 \
         else "256x256 ReLU MLP actor/critics"
     return {"step_fn": lambda k: tr.step(True), "env": tr.env, "trainer": tr,
@@ -260,7 +269,8 @@ def bench_train(args, world, rank, device):
                                                       "acting": "hierarchical goal policy + safety layer + curiosity bonus (shipped config.yaml)"
                                                       if shipped else "SAC policy",
                                                       "domain_randomisation": "off (shipped env)" if stage is None
-                                                      else f"curriculum stage {stage}: {env_over}"}}}
+                                                      else f"curriculum stage {stage} with the curriculum driver attached "
+                                                           f"(device-side episode statistics): {env_over}"}}}
 
 
 def smoke():
