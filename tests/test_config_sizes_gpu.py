@@ -86,7 +86,8 @@ def test_config4_65536_envs_full_dr_stage5_with_curriculum_driver():
     assert st["episodes"] == host_eps and st["episodes"] > n        # the device-side statistics count what the host counts
     assert 0 <= st["successes"] <= st["episodes"] and st["length_sum"] >= st["episodes"]
     assert 3 in stage_seen and stage_seen[-1] == 4, stage_seen       # the driver advanced to "extreme_robustness" in mid-run
-    assert tr.curriculum_log and tr.curriculum_log[0]["stage_before"] == 3 and tr.curriculum_log[0]["stage_after"] == 4
+    assert tr.curriculum_log[0]["stage_before"] == 3 and tr.curriculum_log[0]["stage_after"] == 3   # < half of the stage elapsed
+    assert any(e["stage_before"] == 3 and e["stage_after"] == 4 for e in tr.curriculum_log), tr.curriculum_log
     assert abs(tr.env.cfg.dr_wind_std - 3.0) < 1e-12 and abs(tr.env.cfg.dr_mass_var - 0.3) < 1e-12 \
         and abs(tr.env.cfg.dr_init_tilt_max - 0.7) < 1e-12          # stage 5 ranges are live in the env handle
     # envs that restarted after the change carry stage-5 draws: mass scale in 1 +- 0.3 with sd ~ 0.3 / sqrt 3, wind sd ~ 3 N
@@ -102,7 +103,7 @@ def test_config4_65536_envs_full_dr_stage5_with_curriculum_driver():
     assert np.all(np.isfinite(tr.sac.losses.cpu().numpy())) and torch.isfinite(tr.sac.params).all()
     parity_log.record("config4_65536_envs_dr_stage5_curriculum", envs=n, episodes=st["episodes"], successes=st["successes"],
                       mean_return=st["return_sum"] / st["episodes"], mean_length=st["length_sum"] / st["episodes"],
-                      curriculum_log=tr.curriculum_log[:3], mass_scale_sd=float(ms.std()), wind_sd=float(wx.std()))
+                      curriculum_log=tr.curriculum_log[:4], mass_scale_sd=float(ms.std()), wind_sd=float(wx.std()))
     tr.close()
 
 

@@ -295,11 +295,15 @@ def test_fused_linear_kernel_vs_torch_fp32(M, N, K):
 
 
 def test_checkpoint_layout_and_round_trip(tmp_path):
-    """save_checkpoint keeps the reference's key layout (agent/multi_algorithm_agent.py:1098-1141) and tensor shapes
-    (names/shapes of the reference nets: tests/golden/sac_ref_meta.json); load -> identical deterministic actions
-    (the reference's own integration test asks for atol 1e-6) and identical next update."""
+    """save_checkpoint writes the reference's file layout (agent/multi_algorithm_agent.py:1098-1141): every key, shape and
+    dtype of the MANIFEST taken from a file the reference's own save_checkpoint wrote (tests/golden/ckpt_ref_manifest.json),
+    optimizer_{policy,q1,q2}_state in torch.optim.Adam.state_dict() layout included; load -> identical deterministic actions
+    (the reference's own integration test asks for atol 1e-6), identical moments and step counters.  The reference's own
+    load_checkpoint reading such a file is tested in the build container (tests/test_checkpoint_cpu.py)."""
+    import collections
+    from tvc_ai_amd import checkpoint as ckpt
     from tvc_ai_amd.agent import MultiAlgorithmAgent
-    meta = json.load(open(os.path.join(HERE, "golden", "sac_ref_meta.json")))
+    man = json.load(open(os.path.join(HERE, "golden", "ckpt_ref_manifest.json")))
     cfg = {"tvc_native": {"batch_size": 32, "max_act_rows": 64}}
     a = MultiAlgorithmAgent(10, 2, cfg, seed=1)
     g = torch.Generator().manual_seed(0)
@@ -308,26 +312,55 @@ def test_checkpoint_layout_and_round_trip(tmp_path):
                   "dones": torch.rand(32, generator=g) < 0.1}
     for _ in range(3):
         assert "error" not in a.update(mk())
+    a.update_performance("sac", np.float64(12.5))  # numpy scalars end up in the deques (scripts/train.py:606)
     path = str(tmp_path / "ckpt.pth")
     a.save_checkpoint(path)
-    ck = torch.load(path, map_location="cpu", weights_only=True)
+    ck = ckpt.load_file(path)
+    assert list(ck.keys()) == man["top_level_keys"]
+    assert isinstance(ck["performance_history"]["sac"], collections.deque) and ck["performance_history"]["sac"].maxlen == 100
     sac = ck["algorithms"]["sac"]
-    assert set(sac) >= {"policy_state", "q1_state", "q2_state", "target_q1_state", "target_q2_state", "type"} and sac["type"] == "sac"
-    assert set(ck) >= {"algorithms", "performance_history", "algorithm_weights", "config"}
-    for net, key in (("policy", "policy_state"), ("q1", "q1_state"), ("q2", "q2_state")):
-        for name, shape in meta["nets"][net]:
-            if name.startswith("value_head"):
-                continue  # never created by the SAC path unless imported from a reference checkpoint
-            assert name in sac[key] and list(sac[key][name].shape) == shape, (net, name)
-    assert sac["native_adam"]["steps"] == [3, 3]
+    assert list(sac.keys()) == man["sac_keys"] and sac["type"] == "sac"
+    for net, desc in man["nets"].items():
+        got = [[k, list(t.shape), str(t.dtype).replace("torch.", "")] for k, t in sac[f"{net}_state"].items()]
+        assert got == desc["state_dict"], net
+    for opt, desc in man["optimizers"].items():
+        od = sac[f"{opt}_state"]
+        assert sorted(od["state"].keys()) == sorted(int(i) for i in desc["state"]), opt
+        grp = {k: (list(x) if isinstance(x, (list, tuple)) else x) for k, x in od["param_groups"][0].items()}
+        assert grp == desc["param_groups"][0]
+        assert all(float(st["step"]) == 3.0 for st in od["state"].values())
+        for i, st in od["state"].items():
+            assert [list(st["exp_avg"].shape), "float32"] == desc["state"][str(i)]["exp_avg"], (opt, i)
+    # the dead Q/K rows carry zero moments (the reference's gradient there is exactly zero at sequence length 1)
+    inproj = sac["optimizer_policy_state"]["state"][2]["exp_avg"]
+    assert inproj.shape == (768, 256) and (inproj[:512] == 0).all() and inproj[512:].abs().sum() > 0
     b = MultiAlgorithmAgent(10, 2, cfg, seed=99)
     b.load_checkpoint(path)
     obs = torch.randn(16, 10)
     act_a, _ = a.get_action(obs, deterministic=True)
     act_b, _ = b.get_action(obs, deterministic=True)
     np.testing.assert_allclose(act_a, act_b, atol=1e-6)
-    assert torch.equal(a.sac.params, b.sac.params) and torch.equal(a.sac.adam_v, b.sac.adam_v)
-    assert b.sac.adam_steps() == [3, 3]
+    lay = a.sac.layout
+    for name, off, rows, cols in lay.table:
+        assert torch.equal(lay.view(a.sac.params, name), lay.view(b.sac.params, name)), name
+        if not name.startswith("target_"):
+            assert torch.equal(lay.view(a.sac.adam_m, name), lay.view(b.sac.adam_m, name)), name
+            assert torch.equal(lay.view(a.sac.adam_v, name), lay.view(b.sac.adam_v, name)), name
+    assert b.sac.adam_steps() == [3, 3] and list(b.performance_history["sac"]) == [12.5]
+    # the next update of both agents is the same update
+    batch = mk()
+    la, lb = a.update(batch), b.update(batch)
+    assert "error" not in la and set(la) == set(lb)
+    # a reference-written file holds PPO / TD3 entries and a value head with its own weights: they survive a load + save
+    sac2 = dict(sac)
+    sac2["policy_state"] = collections.OrderedDict(sac["policy_state"])
+    sac2["policy_state"]["value_head.0.weight"] = torch.full((512, 256), 0.25)
+    torch.save({"algorithms": {"ppo": {"type": "ppo"}, "sac": sac2, "td3": {"type": "td3"}},
+                "performance_history": {k: collections.deque([1.0], maxlen=100) for k in ("ppo", "sac", "td3")},
+                "algorithm_weights": {"ppo": 1.0, "sac": 1.0, "td3": 1.0}, "config": {}}, path)
+    b.load_checkpoint(path)
+    b.save_checkpoint(path)
+    assert (ckpt.load_file(path)["algorithms"]["sac"]["policy_state"]["value_head.0.weight"] == 0.25).all()
 
 
 @pytest.mark.parametrize("dropout_p", [0.0, 0.1])

@@ -18,21 +18,13 @@ import numpy as np
 import torch
 
 from . import _native as nat
+from . import checkpoint as ckpt
+from .checkpoint import positional_encoding_table  # noqa: F401  (re-exported: tests and hierarchical.py import it from here)
 
 
 SacCfg = nat.SacCfg
 
 AUTO_COUNTER = (1 << 64) - 1
-
-
-def positional_encoding_table(rows: int, d_model: int) -> torch.Tensor:
-    """PositionalEncoding.pe rows 0..rows-1 (agent/multi_algorithm_agent.py:93-102), a constant buffer."""
-    pe = torch.zeros(rows, d_model)
-    position = torch.arange(0, rows, dtype=torch.float).unsqueeze(1)
-    div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-np.log(10000.0) / d_model))
-    pe[:, 0::2] = torch.sin(position * div_term)
-    pe[:, 1::2] = torch.cos(position * div_term)
-    return pe.contiguous()
 
 
 def sac_cfg(family: int = 0, **over) -> SacCfg:
@@ -84,6 +76,7 @@ class NativeSAC:
             raise nat.TvcError("NativeSAC needs a GPU device: there is no CPU fallback")
         self.table = tensor_table(self.cfg)
         self.index = {n: (o, r, c) for n, o, r, c in self.table}
+        self.layout = ckpt.Layout(self.table, self.cfg.family, self.cfg.d_model, self.cfg.n_layers)
         n_all = self.L.tvc_sac_param_count(C.byref(self.cfg))
         n_tr = self.L.tvc_sac_trainable_count(C.byref(self.cfg))
         self.params = torch.zeros(n_all, dtype=torch.float32, device=self.device)
@@ -152,6 +145,8 @@ class NativeSAC:
             else:  # kaiming_uniform(a=sqrt 5) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
                 t.uniform_(-1 / math.sqrt(cols), 1 / math.sqrt(cols), generator=g)
             self.view(name).copy_(t)
+        if self.cfg.family == 0:  # the reference tensors SAC never executes (Q/K projection rows, value head, PE buffer)
+            self.passive = ckpt.default_passive(self.cfg.d_model, self.cfg.n_layers, self.cfg.head1, self.cfg.head2, seed)
         self.sync_targets()
 
     def _is_ln_bias(self, name):
@@ -201,38 +196,26 @@ class NativeSAC:
 
     def export_reference_state(self, net: str) -> Dict[str, torch.Tensor]:
         """Reference-keyed state_dict of one net (checkpoint compatibility, agent/...:1098-1141)."""
-        d = self.cfg.d_model
-        out = {}
-        if net == "policy" and self.cfg.family == 0:
-            out["input_embedding.weight"] = self.view("policy.input_embedding.weight").cpu().clone()
-            out["input_embedding.bias"] = self.view("policy.input_embedding.bias").cpu().clone()
-            out["pos_encoding.pe"] = self.passive.get("policy.pos_encoding.pe",
-                                                      positional_encoding_table(5000, d).unsqueeze(1))
-            for l in range(self.cfg.n_layers):
-                rp, npfx = f"transformer_encoder.layers.{l}.", f"policy.layers.{l}."
-                for kind in ("weight", "bias"):
-                    key = rp + f"self_attn.in_proj_{kind}"
-                    full = self.passive.get("policy." + key)
-                    if full is None:
-                        full = torch.zeros((3 * d, d) if kind == "weight" else (3 * d,))
-                        if kind == "weight":
-                            torch.nn.init.xavier_uniform_(full)
-                    full = full.clone()
-                    full[2 * d:3 * d] = self.view(npfx + f"v_proj.{kind}").cpu()
-                    out[key] = full
-                    out[rp + f"self_attn.out_proj.{kind}"] = self.view(npfx + f"out_proj.{kind}").cpu().clone()
-                    for m in ("linear1", "linear2", "norm1", "norm2"):
-                        out[rp + f"{m}.{kind}"] = self.view(npfx + f"{m}.{kind}").cpu().clone()
-            for kind in ("weight", "bias"):
-                out[f"feature_norm.{kind}"] = self.view(f"policy.feature_norm.{kind}").cpu().clone()
-                for i in (0, 2, 4, 6, 8):
-                    out[f"policy_head.{i}.{kind}"] = self.view(f"policy.policy_head.{i}.{kind}").cpu().clone()
-            for k, v in self.passive.items():
-                if k.startswith("policy.value_head"):
-                    out[k[len("policy."):]] = v.clone()
-            return out
-        pre = net + "."
-        return {n[len(pre):]: self.view(n).cpu().clone() for n, _, _, _ in self.table if n.startswith(pre)}
+        flat = self.params.detach().cpu()
+        return {k: ckpt._expand(self.layout, flat, k, native, self.passive) for k, native, _ in self.layout.net_keys(net)}
+
+    def export_checkpoint_entry(self) -> dict:
+        """checkpoint['algorithms']['sac'] exactly as the reference's save_checkpoint lays it out (agent/...:1114-1125)"""
+        torch.cuda.synchronize(self.device)
+        return ckpt.pack_sac(self.layout, self.params, self.adam_m, self.adam_v, self.adam_steps(), self.passive)
+
+    def import_checkpoint_entry(self, entry: dict):
+        """the inverse; accepts files written by the reference itself (value_head / Q-K rows are kept for re-export)"""
+        p, m, v = self.params.detach().cpu(), self.adam_m.detach().cpu(), self.adam_v.detach().cpu()
+        steps, passive, have_opt = ckpt.unpack_sac(self.layout, entry, p, m, v)
+        self.params.copy_(p)
+        self.passive.update({k: t for k, t in passive.items() if k.startswith("policy.")})
+        if have_opt:
+            self.adam_m.copy_(m)
+            self.adam_v.copy_(v)
+            self.set_adam_steps(steps)
+        self.sync_derived()
+        return have_opt
 
     # -- hot path
     def snapshot_policy(self):
@@ -470,33 +453,29 @@ class MultiAlgorithmAgent:
                 recent = np.mean(list(self.performance_history[algorithm])[-10:])
                 self.algorithm_weights[algorithm] = max(0.1, recent)
 
-    # checkpoint layout of agent/...:1098-1141 (keys: algorithms.sac.{policy_state,...}, performance_history, ...)
+    # checkpoint layout of agent/...:1098-1141: keys algorithms.sac.{policy_state, q1_state, q2_state, target_q1_state,
+    # target_q2_state, optimizer_policy_state, optimizer_q1_state, optimizer_q2_state, type}, performance_history (dict of
+    # deques, :1102), algorithm_weights, config.  The reference's own load_checkpoint reads a file written here (tested in the
+    # build container against the reference class, tests/test_checkpoint_cpu.py), and a file the reference wrote loads here.
     def save_checkpoint(self, path: str):
-        s = self.sac
-        n0, nc = s.n_policy, s.n_critic
-        ckpt = {
-            "algorithms": {"sac": {
-                "policy_state": s.export_reference_state("policy"),
-                "q1_state": s.export_reference_state("q1"), "q2_state": s.export_reference_state("q2"),
-                "target_q1_state": s.export_reference_state("target_q1"),
-                "target_q2_state": s.export_reference_state("target_q2"),
-                "native_adam": {"m": s.adam_m.cpu(), "v": s.adam_v.cpu(), "steps": s.adam_steps()},
-                "type": "sac"}},
-            "performance_history": {k: list(v) for k, v in self.performance_history.items()},
+        ckpt_dict = {
+            "algorithms": {"sac": self.sac.export_checkpoint_entry()},
+            "performance_history": dict(self.performance_history),
             "algorithm_weights": self.algorithm_weights,
             "config": self.config,
         }
-        torch.save(ckpt, path)
+        torch.save(ckpt_dict, path)
+        self.logger.info(f"Checkpoint saved to {path}")
 
     def load_checkpoint(self, path: str):
-        ckpt = torch.load(path, map_location="cpu", weights_only=True)
-        self.performance_history = {k: deque(v, maxlen=100) for k, v in ckpt["performance_history"].items()}
-        self.algorithm_weights = ckpt["algorithm_weights"]
-        d = ckpt["algorithms"]["sac"]
-        for net in ("policy", "q1", "q2", "target_q1", "target_q2"):
-            self.sac.load_reference_state(net, d[f"{net}_state"])
-        if "native_adam" in d:
-            self.sac.adam_m.copy_(d["native_adam"]["m"])
-            self.sac.adam_v.copy_(d["native_adam"]["v"])
-            if "steps" in d["native_adam"]:
-                self.sac.set_adam_steps(d["native_adam"]["steps"])
+        c = ckpt.load_file(path)  # weights-only loader, deque allow-listed
+        self.performance_history = {k: deque(v, maxlen=100) for k, v in c["performance_history"].items()}
+        self.algorithm_weights = c["algorithm_weights"]
+        entry = c["algorithms"]["sac"]
+        have_opt = self.sac.import_checkpoint_entry(entry)
+        if not have_opt and "native_adam" in entry:  # round-1 files
+            self.sac.adam_m.copy_(entry["native_adam"]["m"])
+            self.sac.adam_v.copy_(entry["native_adam"]["v"])
+            if "steps" in entry["native_adam"]:
+                self.sac.set_adam_steps(entry["native_adam"]["steps"])
+        self.logger.info(f"Checkpoint loaded from {path}")
