@@ -69,11 +69,15 @@ def test_train_loop_with_the_shipped_acting_path():
     tr.close()
 
 
-def test_checkpoint_resume_continues_the_same_run(tmp_path):
+@pytest.mark.parametrize("shipped", [False, True])
+def test_checkpoint_resume_continues_the_same_run(tmp_path, shipped):
     """learner + env SoA state + observations + replay (rows, counters, Philox key) + RNG round-trip: a fresh trainer built with
-    a DIFFERENT seed and loaded from the checkpoint continues like the original (equal to float-atomic summation order)"""
+    a DIFFERENT seed and loaded from the checkpoint continues like the original (equal to float-atomic summation order).
+    shipped: with the curiosity / hierarchical / safety nets of the shipped config, whose weights come from the constructor seed
+    and therefore must travel in the checkpoint."""
     from tvc_ai_amd.trainer import VecTrainer
-    kw = dict(family=1, batch_size=64, replay_capacity=4096, overlap=True)
+    kw = dict(family=1, batch_size=64, replay_capacity=4096, overlap=True, enable_curiosity=shipped, enable_hierarchical=shipped,
+              enable_safety=shipped)
     a = VecTrainer(256, seed=21, **kw)
     for _ in range(6):
         a.step(True)
@@ -95,5 +99,11 @@ def test_checkpoint_resume_continues_the_same_run(tmp_path):
     ra, ma = a.rb.export()
     rbb, mb = b.rb.export()
     assert ma == mb and torch.allclose(ra, rbb, atol=1e-5)
+    if shipped:
+        assert torch.equal(a.curiosity.params, b.curiosity.params) and torch.equal(a.hier.low.params, b.hier.low.params)
+        c = VecTrainer(256, seed=5, family=1, batch_size=64, replay_capacity=4096)  # built without the acting-path nets
+        with pytest.raises(ValueError, match="curiosity"):
+            c.load_checkpoint(path)
+        c.close()
     a.close()
     b.close()

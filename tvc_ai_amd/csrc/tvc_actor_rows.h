@@ -1,0 +1,282 @@
+// Acting pass of the reference-shape policy as ONE launch: the "row-owner wave" kernel.
+//
+// Replaces, for N rows per call, the policy part of MultiAlgorithmAgent.get_action (agent/multi_algorithm_agent.py:765-789):
+// TransformerPolicyNetwork.forward (:192-227) at sequence length 1 -- embedding + PE(0) + 4 x {attention (= one folded
+// 256x256 Linear), +residual, LayerNorm, FFN 256 -> 512 GELU -> 256, +residual, LayerNorm}, feature LayerNorm,
+// policy head 256 -> 512 -> 512 (GELU, LayerNorm) -> 2A -- followed by the Gaussian sample and clamp.
+//
+// Why one kernel: measured per layer, the 64x64 / 32-row LDS-tiled kernels take about (MFMA time + HBM time of the layer's
+// activations): every layer reads and writes a [N, 256..512] fp32 activation (2.9 GB per pass at 65 536 rows) and the two phases
+// do not overlap.  Here no activation ever leaves the CU.
+//
+// Design (gfx950): a wavefront owns 16 rows for the whole network.  Every Linear is computed TRANSPOSED,
+//     out^T[n, m] = sum_k W[n, k] x[m, k],
+// with v_mfma_f32_16x16x4_f32: A operand = a weight fragment (lane l: W[n = l % 16][k = l / 16]), B operand = the activation
+// (lane l: x[m = l % 16][k = l / 16]).  The accumulator of that product holds out[m = l % 16][n = 16 t + 4 (l / 16) + r]
+// (tile t, register r) -- which is exactly the B-operand layout of the NEXT Linear when its k-tile t / k-step r consumes register
+// (t, r).  So activations chain from accumulator registers to operand registers with no shuffle, no LDS round trip and no
+// cross-wave exchange; residual adds, GELU and LayerNorm are lane-local (+ two xor-shuffles per row statistic).
+// Only weights move: all passes read one pre-packed stream of 16 KB tiles (image[q][n] = W[n0 + n][k0 + 4 q .. + 3], built by
+// pack_actor_kernel after every policy update) through a two-buffer LDS ring filled by global_load_lds_dwordx4 one tile ahead,
+// one s_barrier per tile; the four waves of a workgroup (64 rows) share each tile.  A tile is 16 conflict-free ds_read_b128 and
+// 64 MFMAs per wave.
+#pragma once
+#include "tvc_nn_kernels.h"
+
+namespace tvcnn {
+
+constexpr int AR_TILE_F4 = 1024;    // float4 per weight tile: 4 k-quads x 256 output features
+constexpr int AR_LAYER_VEC = 2048;  // floats per encoder layer in the vector section
+// vector section, encoder layer l at l * AR_LAYER_VEC:
+//   +0 attention bias b_ov (layer 0: b' of the folded embedding)   +256 norm1 gamma   +512 norm1 beta
+//   +768 linear1 bias (512)   +1280 linear2 bias   +1536 norm2 gamma   +1792 norm2 beta
+// tail at n_layers * AR_LAYER_VEC:
+//   +0 feature_norm gamma  +256 beta  +512 head.0 bias (512)  +1024 head.2 gamma  +1536 head.2 beta  +2048 head.4 bias
+//   +2560 head.6 gamma  +3072 head.6 beta  +3584 head.8 weight [4][512] (rows >= 2A zero)  +5632 head.8 bias [4]
+constexpr int AR_TAIL_VEC = 5648;
+
+struct ActRowsArgs {
+    const float* obs; const float* eps;          // [M, obs_dim], [M, A] or nullptr (deterministic)
+    float* act; float* mean; float* logstd;      // [M, A]; mean / logstd may be nullptr
+    const float4* tiles; const float* vec;       // packed weights
+    int M, obs_dim, A, clamp_act, n_layers, n_tiles;
+};
+
+struct ArPipe {
+    const float4* tiles; float4* Bs;
+    int ti, n_tiles, wave, lane;
+};
+__device__ __forceinline__ void ar_issue_tile(const ArPipe& p, int ti) {
+    // 16 KB = 4 waves x 4 wave-instructions x 1 KB, lane-linear image: LDS byte i of the tile = global byte i
+    const float4* src = p.tiles + (long)ti * AR_TILE_F4 + p.wave * 256 + p.lane;
+    float4* dst = p.Bs + (ti & 1) * AR_TILE_F4 + p.wave * 256;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 64),
+                                         (__attribute__((address_space(3))) void*)(dst + j * 64), 16, 0, 0);
+}
+// make tile p.ti readable, start the copy of tile p.ti + 1 into the other buffer, return the readable tile
+__device__ __forceinline__ const float4* ar_next(ArPipe& p) {
+    // my quarter of tile ti has landed; the barrier says everyone's has, and that everyone is done reading tile ti - 1
+    // (lgkmcnt(0): fragment reads of tile ti - 1 that the compiler issued late have returned before anyone refills their buffer)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const float4* cur = p.Bs + (p.ti & 1) * AR_TILE_F4;
+    if (p.ti + 1 < p.n_tiles) ar_issue_tile(p, p.ti + 1);
+    p.ti += 1;
+    return cur;
+}
+// acc[t] (t = 0..15: output features 16 t + 4 q + r of this lane's row) += W_tile . x_k^T for one 16-deep k-tile
+__device__ __forceinline__ void ar_tile(const float4* __restrict__ cur, const f32x4 xk, f32x4* __restrict__ acc, int l15, int q) {
+    const float4* base = cur + q * 256 + l15;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float4 w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = base[(4 * g + j) * 16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float wv = c == 0 ? w[j].x : (c == 1 ? w[j].y : (c == 2 ? w[j].z : w[j].w));
+                acc[4 * g + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xk[c], acc[4 * g + j], 0, 0, 0);
+            }
+    }
+}
+template <int KT>
+__device__ __forceinline__ void ar_pass(ArPipe& p, const f32x4* __restrict__ x, f32x4* __restrict__ acc, int l15, int q) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        const float4* cur = ar_next(p);
+        ar_tile(cur, x[kt], acc, l15, q);
+    }
+}
+__device__ __forceinline__ f32x4 ar_vec4(const float* __restrict__ v, int t, int q) {
+    return *reinterpret_cast<const f32x4*>(v + 16 * t + 4 * q);
+}
+template <int NT>
+__device__ __forceinline__ void ar_zero(f32x4* u) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) u[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+// nn.LayerNorm over the 16 * NT features of each row (eps 1e-5, two-pass like torch); a row lives in the 4 lanes l15 + 16 q
+template <int NT>
+__device__ __forceinline__ void ar_layernorm(f32x4* __restrict__ u, const float* __restrict__ gamma, const float* __restrict__ beta, int q) {
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s += (u[t][0] + u[t][1]) + (u[t][2] + u[t][3]);
+    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+    const float mean = s * (1.0f / (16.0f * NT));
+    float v = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = u[t][r] - mean; v = fmaf(d, d, v); }
+    v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    const float rstd = rsqrtf(v * (1.0f / (16.0f * NT)) + 1e-5f);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 g4 = ar_vec4(gamma, t, q), b4 = ar_vec4(beta, t, q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[t][r] = (u[t][r] - mean) * rstd * g4[r] + b4[r];
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
+    __shared__ __attribute__((aligned(16))) float4 Bs[2 * AR_TILE_F4];  // the ONLY LDS object: two 16 KB weight-tile buffers
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * 64 + wave * 16 + l15;
+    const int rowc = min(row, a.M - 1);
+    ArPipe p{a.tiles, Bs, 0, a.n_tiles, wave, lane};
+    ar_issue_tile(p, 0);
+
+    // observation as the first B operand: x[m][k = 4 q + r], zero beyond obs_dim (clamped address, selected after the load)
+    f32x4 xin;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = 4 * q + r;
+        const float v = a.obs[(long)rowc * a.obs_dim + min(k, a.obs_dim - 1)];
+        xin[r] = k < a.obs_dim ? v : 0.0f;
+    }
+    const float* vec = a.vec;
+    f32x4 x[16];
+    // ---- layer 0, first sublayer: embedding + PE(0) + folded attention + residual as ONE obs -> 256 Linear, then norm1
+    {
+        ar_zero<16>(x);
+        const float4* cur = ar_next(p);
+        ar_tile(cur, xin, x, l15, q);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) x[t] += ar_vec4(vec, t, q);
+        ar_layernorm<16>(x, vec + 256, vec + 512, q);
+    }
+    for (int l = 0; l < a.n_layers; ++l) {
+        const float* lv = vec + l * AR_LAYER_VEC;
+        if (l > 0) {  // x = norm1(x + W_ov x + b_ov)
+            f32x4 acc[16];
+            ar_zero<16>(acc);
+            ar_pass<16>(p, x, acc, l15, q);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) x[t] += acc[t] + ar_vec4(lv, t, q);
+            ar_layernorm<16>(x, lv + 256, lv + 512, q);
+        }
+        // x = norm2(x + W2 gelu(W1 x + b1) + b2), the 512 hidden units in two halves: the hidden half never leaves registers
+        f32x4 acc2[16];
+        ar_zero<16>(acc2);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 h[16];
+            ar_zero<16>(h);
+            ar_pass<16>(p, x, h, l15, q);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const f32x4 b4 = ar_vec4(lv + 768 + 256 * half, t, q);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[t][r] = gelu_f(h[t][r] + b4[r]);
+            }
+            ar_pass<16>(p, h, acc2, l15, q);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) x[t] += acc2[t] + ar_vec4(lv + 1280, t, q);
+        ar_layernorm<16>(x, lv + 1536, lv + 1792, q);
+    }
+    const float* tv = vec + a.n_layers * AR_LAYER_VEC;
+    ar_layernorm<16>(x, tv, tv + 256, q);  // feature_norm
+    // ---- policy head: 256 -> 512 GELU LayerNorm
+    f32x4 pp[32];
+    ar_zero<32>(pp);
+    ar_pass<16>(p, x, pp, l15, q);
+    ar_pass<16>(p, x, pp + 16, l15, q);
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const f32x4 b4 = ar_vec4(tv + 512, t, q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pp[t][r] = gelu_f(pp[t][r] + b4[r]);
+    }
+    ar_layernorm<32>(pp, tv + 1024, tv + 1536, q);
+    // ---- 512 -> 512 GELU LayerNorm -> 2A outputs.  The LayerNorm and the output Linear are folded into running sums:
+    //   out[o] = rstd (sum_n g_n gamma_n W[o,n] - mean sum_n gamma_n W[o,n]) + sum_n beta_n W[o,n] + b[o],  g = gelu(.)
+    // so the second 512-wide activation is never held (one-pass variance E[g^2] - mean^2 on O(1) values)
+    float s1 = 0.0f, s2 = 0.0f, d[4] = {0.f, 0.f, 0.f, 0.f}, gs[4] = {0.f, 0.f, 0.f, 0.f}, es[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x4 a2[16];
+        ar_zero<16>(a2);
+        ar_pass<32>(p, pp, a2, l15, q);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int tt = 16 * half + t;
+            const f32x4 b4 = ar_vec4(tv + 2048, tt, q), g4 = ar_vec4(tv + 2560, tt, q), be4 = ar_vec4(tv + 3072, tt, q);
+            f32x4 wh[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) wh[o] = ar_vec4(tv + 3584 + 512 * o, tt, q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = gelu_f(a2[t][r] + b4[r]);
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const float gw = g4[r] * wh[o][r];
+                    d[o] = fmaf(v, gw, d[o]);
+                    gs[o] += gw;
+                    es[o] = fmaf(be4[r], wh[o][r], es[o]);
+                }
+            }
+        }
+    }
+#define AR_RED(v) v += __shfl_xor(v, 16); v += __shfl_xor(v, 32)
+    AR_RED(s1); AR_RED(s2);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) { AR_RED(d[o]); AR_RED(gs[o]); AR_RED(es[o]); }
+#undef AR_RED
+    const float mean = s1 * (1.0f / 512.0f);
+    const float rstd = rsqrtf(fmaxf(s2 * (1.0f / 512.0f) - mean * mean, 0.0f) + 1e-5f);
+    float out[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) out[o] = rstd * (d[o] - mean * gs[o]) + es[o] + tv[5632 + o];
+    // mean, clamped log_std, action = mean + exp(log_std) eps  (agent/...:224-225, 780-782, 789)
+    if (q == 0 && row < a.M) {
+        for (int j = 0; j < a.A; ++j) {
+            const float mu = out[j];
+            const float ls = fminf(fmaxf(out[a.A + j], -20.0f), 2.0f);
+            const long i = (long)row * a.A + j;
+            float av = a.eps ? mu + expf(ls) * a.eps[i] : mu;
+            if (a.clamp_act) av = fminf(fmaxf(av, -1.0f), 1.0f);
+            a.act[i] = av;
+            if (a.mean) a.mean[i] = mu;
+            if (a.logstd) a.logstd[i] = ls;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ weight packing
+struct PackTile { long src; int ld, k0, kvalid, from_ov; };   // src: float offset of W[n0][0] in the parameter / derived buffer
+struct PackVec { long src; int dst, count, from_ov; };
+__global__ void __launch_bounds__(256) pack_actor_kernel(const float* __restrict__ P, const float* __restrict__ OV,
+                                                         const PackTile* __restrict__ tiles, int n_tiles,
+                                                         const PackVec* __restrict__ vecs, float4* __restrict__ out_tiles,
+                                                         float* __restrict__ out_vec) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b < n_tiles) {
+        const PackTile t = tiles[b];
+        const float* base = (t.from_ov ? OV : P) + t.src;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = j * 256 + tid, qq = idx >> 8, n = idx & 255;
+            const int k = t.k0 + 4 * qq;
+            const float* r = base + (long)n * t.ld;
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float w = r[min(k + c, t.kvalid - 1)];
+                v[c] = (k + c) < t.kvalid ? w : 0.0f;
+            }
+            out_tiles[(long)b * AR_TILE_F4 + idx] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    } else {
+        const PackVec e = vecs[b - n_tiles];
+        const float* src = (e.from_ov ? OV : P) + e.src;
+        for (int i = tid; i < e.count; i += 256) out_vec[e.dst + i] = src[i];
+    }
+}
+
+}  // namespace tvcnn

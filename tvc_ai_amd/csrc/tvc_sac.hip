@@ -18,6 +18,7 @@
 
 #include "tvc_common.h"
 #include "tvc_nn_kernels.h"
+#include "tvc_actor_rows.h"
 
 using namespace tvcnn;
 
@@ -764,12 +765,79 @@ struct tvc_sac {
     bool grads_clean[2] = {false, false};  // critics, actor: zeroed by the Adam kernel since they were last written
     float *pe = nullptr, *xcat = nullptr, *a_tmp = nullptr, *y = nullptr, *dq = nullptr, *ls_tmp = nullptr, *mean_tmp = nullptr;
     AdamClock* clk = nullptr;  // [2]: critics, actor
+    // one-launch acting pass (tvc_actor_rows.h): packed weight-tile stream + vector section, rebuilt after every policy update
+    bool rows_ok = false;
+    int rows_tiles = 0, rows_vecs = 0;
+    long pack_floats = 0;
+    float *pack = nullptr, *snap_pack = nullptr;  // [rows_tiles * 4096 tile floats | vector section]
+    PackTile* d_ptiles = nullptr;
+    PackVec* d_pvecs = nullptr;
     float* P_actor() { return params; }
     float* P_q() { return params + n_actor; }
     float* P_tq() { return params + n_actor + 2 * n_critic; }
     float* G_actor() { return grads; }
     float* G_q() { return grads + n_actor; }
 };
+
+// The acting megakernel covers the reference shapes with the embedding folded (PE(0) on every row): everything else keeps
+// the per-layer kernels.
+static bool rows_supported(const tvc_sac_cfg& c, const FoldInfo& f) {
+    return c.family == 0 && f.embed && !c.use_se && c.d_model == 256 && c.ff_dim == 512 && c.head1 == 512 && c.head2 == 512 &&
+           2 * c.act_dim <= 4 && c.obs_dim <= 16 && f.layers == c.n_layers && c.pe_rows == 1;
+}
+static int rows_min_rows() {  // acting batches at least this large take the one-launch path (64 rows per workgroup)
+    static const int v = [] { const char* e = getenv("TVC_ROWS_MIN"); return e ? atoi(e) : 8192; }();
+    return v;
+}
+// Descriptor tables of pack_actor_kernel: the tile stream in the order actor_rows_kernel consumes it, and the vector section.
+static void rows_tables(const tvc_sac_cfg& c, const NetDef& actor, const FoldInfo& f, std::vector<PackTile>& tiles,
+                        std::vector<PackVec>& vecs) {
+    auto off = [&](const std::string& name) -> long {
+        for (const TensorInfo& t : actor.tensors)
+            if (t.name == name) return t.off;
+        return -1;
+    };
+    const int d = 256;
+    const long ostride = (long)d * d + d;
+    auto pass = [&](long src, int ld, int n0, int k0, int ktiles, int kvalid, int from_ov) {
+        for (int kt = 0; kt < ktiles; ++kt) tiles.push_back(PackTile{src + (long)n0 * ld, ld, k0 + 16 * kt, kvalid, from_ov});
+    };
+    auto vec = [&](long src, int dst, int count, int from_ov) { vecs.push_back(PackVec{src, dst, count, from_ov}); };
+    for (int l = 0; l < c.n_layers; ++l) {
+        const std::string p = "layers." + std::to_string(l) + ".";
+        const int lv = l * AR_LAYER_VEC;
+        if (l == 0) {
+            pass(f.e_off, f.obs, 0, 0, 1, f.obs, 1);                         // W' [256][obs], one zero-padded 16-deep tile
+            vec(f.e_off + (long)d * f.obs, lv, d, 1);                          // b'
+        } else {
+            pass(l * ostride, d, 0, 0, 16, d, 1);                              // W_ov of layer l
+            vec(l * ostride + (long)d * d, lv, d, 1);                          // b_ov
+        }
+        vec(off(p + "norm1.weight"), lv + 256, d, 0);
+        vec(off(p + "norm1.bias"), lv + 512, d, 0);
+        for (int half = 0; half < 2; ++half) {
+            pass(off(p + "linear1.weight"), d, 256 * half, 0, 16, d, 0);       // hidden units [256 half, +256) <- x
+            pass(off(p + "linear2.weight"), 512, 0, 256 * half, 16, 512, 0);   // out += W2[:, hidden half] h
+        }
+        vec(off(p + "linear1.bias"), lv + 768, 512, 0);
+        vec(off(p + "linear2.bias"), lv + 1280, d, 0);
+        vec(off(p + "norm2.weight"), lv + 1536, d, 0);
+        vec(off(p + "norm2.bias"), lv + 1792, d, 0);
+    }
+    const int tv = c.n_layers * AR_LAYER_VEC;
+    vec(off("feature_norm.weight"), tv, d, 0);
+    vec(off("feature_norm.bias"), tv + 256, d, 0);
+    for (int half = 0; half < 2; ++half) pass(off("policy_head.0.weight"), d, 256 * half, 0, 16, d, 0);
+    vec(off("policy_head.0.bias"), tv + 512, 512, 0);
+    vec(off("policy_head.2.weight"), tv + 1024, 512, 0);
+    vec(off("policy_head.2.bias"), tv + 1536, 512, 0);
+    for (int half = 0; half < 2; ++half) pass(off("policy_head.4.weight"), 512, 256 * half, 0, 32, 512, 0);
+    vec(off("policy_head.4.bias"), tv + 2048, 512, 0);
+    vec(off("policy_head.6.weight"), tv + 2560, 512, 0);
+    vec(off("policy_head.6.bias"), tv + 3072, 512, 0);
+    vec(off("policy_head.8.weight"), tv + 3584, 2 * c.act_dim * 512, 0);      // rows >= 2A stay zero (the slab is zero-filled)
+    vec(off("policy_head.8.bias"), tv + 5632, 2 * c.act_dim, 0);
+}
 
 static long ctx_bytes(const NetDef& nd, int M, int G, bool train) {
     long f = 0;
@@ -908,6 +976,17 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     h->ov_floats = (long)std::max(1, h->fold.layers) * ((long)h->fold.d * h->fold.d + h->fold.d + 4) +
                    (long)h->fold.d * (h->fold.obs + 1) + 8;
     bytes += 2 * h->ov_floats * 4 + h->n_actor * 4 + 2048;
+    std::vector<PackTile> ptiles;
+    std::vector<PackVec> pvecs;
+    h->rows_ok = rows_supported(*cfg, h->fold);
+    if (h->rows_ok) {
+        rows_tables(*cfg, h->actor, h->fold, ptiles, pvecs);
+        for (const PackVec& v : pvecs) h->rows_ok = h->rows_ok && v.src >= 0;
+        for (const PackTile& t : ptiles) h->rows_ok = h->rows_ok && t.src >= 0;
+        h->rows_tiles = (int)ptiles.size(); h->rows_vecs = (int)pvecs.size();
+        h->pack_floats = (long)h->rows_tiles * 4096 + (long)cfg->n_layers * AR_LAYER_VEC + AR_TAIL_VEC;
+        bytes += 2 * h->pack_floats * 4 + ptiles.size() * sizeof(PackTile) + pvecs.size() * sizeof(PackVec) + 2048;
+    }
     hipError_t he = hipMalloc(&h->slab, bytes);
     if (he != hipSuccess) {
         delete h;
@@ -934,6 +1013,12 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     h->ov = (float*)carve(p, h->ov_floats * 4);
     h->snap_ov = (float*)carve(p, h->ov_floats * 4);
     h->snap_p = (float*)carve(p, h->n_actor * 4);
+    if (h->rows_ok) {
+        h->pack = (float*)carve(p, h->pack_floats * 4);
+        h->snap_pack = (float*)carve(p, h->pack_floats * 4);
+        h->d_ptiles = (PackTile*)carve(p, ptiles.size() * sizeof(PackTile));
+        h->d_pvecs = (PackVec*)carve(p, pvecs.size() * sizeof(PackVec));
+    }
     if ((long)(p - (char*)h->slab) > bytes) {
         (void)hipFree(h->slab);
         delete h;
@@ -950,6 +1035,15 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
             (void)hipFree(h->slab);
             delete h;
             return tvc::set_error(TVC_EHIP, "hipMemcpy(pe) failed: %s", hipGetErrorString(he));
+        }
+    }
+    if (h->rows_ok) {
+        he = hipMemcpy(h->d_ptiles, ptiles.data(), ptiles.size() * sizeof(PackTile), hipMemcpyHostToDevice);
+        if (he == hipSuccess) he = hipMemcpy(h->d_pvecs, pvecs.data(), pvecs.size() * sizeof(PackVec), hipMemcpyHostToDevice);
+        if (he != hipSuccess) {
+            (void)hipFree(h->slab);
+            delete h;
+            return tvc::set_error(TVC_EHIP, "hipMemcpy(pack tables) failed: %s", hipGetErrorString(he));
         }
     }
     {
@@ -982,6 +1076,17 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
     // activation group strides depend on the row count actually used
     for (size_t b = 1; b < h->ictx.gY.size(); ++b) h->ictx.gY[b] = (long)n * h->actor_inf.buf_dim[b];
     const bool snap = (flags & 2) != 0;  // read the snapshot taken by tvc_sac_snapshot_policy instead of the live parameters
+    if (h->rows_ok && n >= rows_min_rows() && g_force_variant == 0) {  // the whole pass as one launch (tvc_actor_rows.h)
+        const float* pk = snap ? h->snap_pack : h->pack;
+        ActRowsArgs a{};
+        a.obs = obs; a.eps = eps; a.act = act; a.mean = mean; a.logstd = logstd;
+        a.tiles = reinterpret_cast<const float4*>(pk); a.vec = pk + (long)h->rows_tiles * 4096;
+        a.M = n; a.obs_dim = h->cfg.obs_dim; a.A = A; a.clamp_act = (flags & 1) ? 0 : 1;
+        a.n_layers = h->cfg.n_layers; a.n_tiles = h->rows_tiles;
+        hipLaunchKernelGGL(actor_rows_kernel, dim3((n + 63) / 64), dim3(256), 0, st, a);
+        TVC_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     net_forward(h->actor_inf, snap ? h->snap_p : h->P_actor(), 0, obs, 0, n, 1, h->ictx, false, h->cfg.family == 0 ? h->pe : nullptr,
                 h->cfg.pe_rows, st, snap ? h->snap_ov : h->ov);
     const float* head = h->ictx.Y.back();
@@ -1134,6 +1239,9 @@ static void refresh_folded(tvc_sac* h, hipStream_t st) {
         hipLaunchKernelGGL(fold_embed_kernel, dim3(d), dim3(256), 0, st, h->P_actor() + f.e_w,
                            h->P_actor() + f.e_b, h->cfg.family == 0 ? h->pe : nullptr, h->ov, h->ov + (long)d * d, h->ov + f.e_off,
                            h->ov + f.e_off + (long)d * f.obs, d, f.obs);
+    if (h->rows_ok)  // re-pack the acting megakernel's weight stream from the fresh parameters / folded weights
+        hipLaunchKernelGGL(pack_actor_kernel, dim3(h->rows_tiles + h->rows_vecs), dim3(256), 0, st, h->P_actor(), h->ov, h->d_ptiles,
+                           h->rows_tiles, h->d_pvecs, reinterpret_cast<float4*>(h->pack), h->pack + (long)h->rows_tiles * 4096);
 }
 
 // Adam step counters (critics, actor) live on the device so that a captured update keeps counting; these two calls
@@ -1169,6 +1277,7 @@ int tvc_sac_snapshot_policy(tvc_sac* h, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     TVC_HIP_CHECK(hipMemcpyAsync(h->snap_p, h->P_actor(), h->n_actor * sizeof(float), hipMemcpyDeviceToDevice, st));
     TVC_HIP_CHECK(hipMemcpyAsync(h->snap_ov, h->ov, h->ov_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (h->rows_ok) TVC_HIP_CHECK(hipMemcpyAsync(h->snap_pack, h->pack, h->pack_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
 }
 

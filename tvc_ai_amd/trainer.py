@@ -207,6 +207,12 @@ class VecTrainer:
             "replay": {"rows": rows.cpu(), "meta": meta, "seed": int(self.rb.seed)},
             "env_seed": int(self.env.cfg.seed),
             "rng": torch.cuda.get_rng_state(self.device),
+            # the never-trained acting-path nets are seeded by the constructor: carry them, so that a trainer built with another
+            # seed resumes with the SAME curiosity bonus / goal policy / safety correction
+            "aux_nets": {k: v.params.cpu() for k, v in (("curiosity", self.curiosity), ("safety", self.safety),
+                                                        ("hier_high", self.hier.high if self.hier is not None else None),
+                                                        ("hier_low", self.hier.low if self.hier is not None else None))
+                         if v is not None},
         }
 
     def load_state_dict(self, sd):
@@ -224,6 +230,18 @@ class VecTrainer:
         if int(sd["env_seed"]) != int(self.env.cfg.seed) and int(self.env.cfg.dr_enabled):
             raise ValueError("domain-randomised envs draw from (seed, env id, episode): build the trainer with the checkpoint's "
                              f"seed {int(sd['env_seed'])} to resume")
+        mine = {"curiosity": self.curiosity, "safety": self.safety,
+                "hier_high": self.hier.high if self.hier is not None else None,
+                "hier_low": self.hier.low if self.hier is not None else None}
+        saved = sd.get("aux_nets", {})
+        for k, net in mine.items():
+            if (net is not None) != (k in saved):
+                raise ValueError(f"checkpoint {'has' if k in saved else 'lacks'} the {k} net but this trainer was built "
+                                 f"{'without' if net is None else 'with'} it")
+            if net is not None:
+                net.params.copy_(saved[k])
+        if self.hier is not None:
+            self.hier.low.sync_derived()
         torch.cuda.set_rng_state(sd["rng"], self.device)
         torch.cuda.synchronize(self.device)
 
