@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--steps-per-launch", type=int, default=1, help="physics: T env steps per kernel launch with pre-supplied actions "
                                                                     "(tvc_env_step_many, the tests/benchmark.py:40-60 procedure); --steps must be a multiple")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline sample length (0 = skip)")
+    ap.add_argument("--loop-only", action="store_true", help="skip the roofline / diagnostic legs and the CPU baseline (profiling runs: "
+                                                             "the kernel statistics then cover the timed loop only)")
     ap.add_argument("--roofline-envs", type=int, default=1 << 22, help="bandwidth-regime size for the extra roofline point")
     return ap.parse_args()
 
@@ -401,10 +403,11 @@ def main():
 
     if rank == 0:
         try:
-            out.update(roofline_report(args, workload, n, step_fn if workload == "physics" else None, dev_us_per_step, device))
+            if not args.loop_only:
+                out.update(roofline_report(args, workload, n, step_fn if workload == "physics" else None, dev_us_per_step, device))
         except Exception as e:  # the headline line must survive a failure of the diagnostic legs
             out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
-        if args.cpu_seconds > 0 and world == 1:  # rank 0 at N = 1 only
+        if args.cpu_seconds > 0 and world == 1 and not args.loop_only:  # rank 0 at N = 1 only
             try:
                 out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, n if workload == "train" else 0)
             except Exception as e:
@@ -498,49 +501,86 @@ def integrator_roofline(n, device, us=None, dr_stage=None, stats=False):
             "algorithmic_bytes_per_launch": per_env * n, "env_steps_per_s": n / (us * 1e-6)}
 
 
+def _layer_kernel_roofline(L, n, device):
+    """Row counts below the one-launch kernel's threshold (or the MLP family): the dominant kernel is the fused Linear +
+    residual + LayerNorm of the per-layer acting pass (K = 512 -> N = 256, M = envs); < 6144 rows the unfused 64x64 kernel."""
+    rep = {}
+    M, N, K = n, 256, 512
+    X = torch.randn(M, K, device=device)
+    W = torch.randn(N, K, device=device) / 16
+    b = torch.zeros(N, device=device)
+    R = torch.randn(M, N, device=device)
+    gam, bet = torch.ones(N, device=device), torch.zeros(N, device=device)
+    Y = torch.empty(M, N, device=device)
+    fused = M >= 6144
+    if fused:
+        kname = "tvcnn::gemm_rowln_kernel<4, 32> (Linear 512->256 + residual + LayerNorm, M = envs)"
+        us = graph_time_us(lambda k: L.tvc_nn_linear_ln_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(),
+                                                                gam.data_ptr(), bet.data_ptr(), Y.data_ptr(), M, N, K, 0,
+                                                                torch.cuda.current_stream(device).cuda_stream), 20, device)
+        traffic = pmc_traffic(((M + 31) // 32) * 256, "tvcnn::gemm_rowln_kernel<4, 32>")
+    else:
+        kname = "tvcnn::gemm_kernel<true,true> (Linear 512->256, M = envs)"
+        us = graph_time_us(lambda k: L.tvc_nn_linear_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, N, K, 0,
+                                                             0, torch.cuda.current_stream(device).cuda_stream), 20, device)
+        traffic = pmc_traffic((N // 64) * ((M + 63) // 64) * 256, "tvcnn::gemm_kernel")
+    tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
+    loop = in_loop_us(kname.split(" (")[0], n)
+    rep["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": tf,
+                       "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                       "traffic": traffic,
+                       "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc pass, not measured in this run)" if traffic else None,
+                       "launch_us": us, "launch_us_source": "live: hipGraph of 20 isolated launches, HIP events on their stream",
+                       "in_loop_us": loop,
+                       "in_loop_source": f"{LOOP_STATS_FILE} (committed rocprofv3 --kernel-trace --stats of the train loop)" if loop else None,
+                       "in_loop_frac": (2.0 * M * N * K / (loop * 1e-6) / 1e12 / MFMA_F32_PEAK_TF) if loop else None,
+                       "flops_per_launch": 2.0 * M * N * K, "dtype": "f32 in / f32 acc MFMA"}
+    return rep
+
+
 def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device):
     rep = {}
     if workload == "physics":
         # the timed region holds exactly K launches of this one kernel: launch duration = HIP-event time / K
         rep["roofline"] = integrator_roofline(n, device, us=dev_us_per_step)
     else:
-        # dominant kernel of the train loop = the fused Linear + residual + LayerNorm of the acting pass (M = envs;
-        # the K = 512 -> N = 256 FFN-out layer is the largest single line of the kernel trace, profiles/), fp32-input
-        # MFMA (v_mfma_f32_16x16x4_f32), dense peak 157.3 TFLOP/s.  Small N (< 6144 rows) runs the unfused 64x64 kernel.
         from tvc_ai_amd import _native as nat
         L = nat.load()
-        M, N, K = n, 256, 512
-        X = torch.randn(M, K, device=device)
-        W = torch.randn(N, K, device=device) / 16
-        b = torch.zeros(N, device=device)
-        R = torch.randn(M, N, device=device)
-        gam, bet = torch.ones(N, device=device), torch.zeros(N, device=device)
-        Y = torch.empty(M, N, device=device)
-        fused = M >= 6144
-        if fused:
-            kname = "tvcnn::gemm_rowln_kernel<4, 32> (Linear 512->256 + residual + LayerNorm, M = envs)"
-            us = graph_time_us(lambda k: L.tvc_nn_linear_ln_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(),
-                                                                    gam.data_ptr(), bet.data_ptr(), Y.data_ptr(), M, N, K, 0,
-                                                                    torch.cuda.current_stream(device).cuda_stream), 20, device)
-            traffic = pmc_traffic(((M + 31) // 32) * 256, "tvcnn::gemm_rowln_kernel<4, 32>")
+        rows_kernel = args.family == 0 and n >= 12288  # the one-launch row-owner acting kernel (csrc/tvc_actor_rows.h)
+        if rows_kernel:
+            # dominant kernel of the train loop = the WHOLE acting pass as one launch: every Linear of the policy on
+            # v_mfma_f32_16x16x4_f32 (dense f32 peak 157.3 TFLOP/s), activations in registers, weights streamed through LDS.
+            # flops per launch = 2 x MACs per row (as executed: embedding folded into layer 0, attention folded to one 256x256
+            # Linear per layer) x rows
+            from tvc_ai_amd.agent import NativeSAC, sac_cfg
+            sacr = NativeSAC(sac_cfg(0, batch_size=256, max_act_rows=n), device=device, seed=2)
+            ob, ep = torch.randn(n, 10, device=device), torch.randn(n, 2, device=device)
+            outs = tuple(torch.empty(n, 2, device=device) for _ in range(3))
+            us = graph_time_us(lambda k: sacr.act(ob, ep, out=outs), 5, device)
+            macs = 16 * 256 + 3 * 256 * 256 + 4 * (2 * 256 * 512) + 256 * 512 + 512 * 512 + 512 * 4
+            flops = 2.0 * macs * n
+            kname = "tvcnn::actor_rows_kernel (policy forward of all rows in one launch: 4 encoder layers + head + sample)"
+            import ctypes as C
+            clk = (C.c_double * 3)()
+            clock = None
+            if L.tvc_debug_rows_clock(sacr._h, ob.data_ptr(), n, 20, clk, torch.cuda.current_stream(device).cuda_stream) == 0:
+                clock = {"in_kernel_mhz": clk[0], "median_workgroup_lifetime_us": clk[1], "workgroups": int(clk[2]),
+                         "f32_mfma_peak_at_that_clock_tflops": clk[0] * 1e6 * 64 * 4 * 256 / 1e12}
+            traffic = pmc_traffic(((n + 63) // 64) * 256, "tvcnn::actor_rows_kernel")
+            sacr.close()
+            del ob, ep, outs
+            tf = flops / (us * 1e-6) / 1e12
+            loop = in_loop_us("tvcnn::actor_rows_kernel", n)
+            rep["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": tf / MFMA_F32_PEAK_TF, "traffic": traffic,
+                               "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc pass, not measured in this run)" if traffic else None,
+                               "launch_us": us, "launch_us_source": "live: hipGraph of 5 isolated launches, HIP events on their stream",
+                               "in_loop_us": loop,
+                               "in_loop_source": f"{LOOP_STATS_FILE} (committed rocprofv3 --kernel-trace --stats of the train loop)" if loop else None,
+                               "in_loop_frac": (flops / (loop * 1e-6) / 1e12 / MFMA_F32_PEAK_TF) if loop else None,
+                               "flops_per_launch": flops, "flops_per_row": 2.0 * macs, "clock": clock, "dtype": "f32 in / f32 acc MFMA"}
         else:
-            kname = "tvcnn::gemm_kernel<true,true> (Linear 512->256, M = envs)"
-            us = graph_time_us(lambda k: L.tvc_nn_linear_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), Y.data_ptr(), M, N, K, 0,
-                                                                 0, torch.cuda.current_stream(device).cuda_stream), 20, device)
-            traffic = pmc_traffic((N // 64) * ((M + 63) // 64) * 256, "tvcnn::gemm_kernel")
-        tf = 2.0 * M * N * K / (us * 1e-6) / 1e12
-        loop = in_loop_us(kname.split(" (")[0], n)
-        rep["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": tf,
-                           "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
-                           "traffic": traffic,
-                           "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc pass, not measured in this run)" if traffic else None,
-                           "launch_us": us, "launch_us_source": "live: hipGraph of 20 isolated launches, HIP events on their stream",
-                           "in_loop_us": loop,
-                           "in_loop_source": f"{LOOP_STATS_FILE} (committed rocprofv3 --kernel-trace --stats of the train loop)" if loop else None,
-                           "in_loop_frac": (2.0 * M * N * K / (loop * 1e-6) / 1e12 / MFMA_F32_PEAK_TF) if loop else None,
-                           "flops_per_launch": 2.0 * M * N * K, "dtype": "f32 in / f32 acc MFMA"}
-        del R, gam, bet
-        del X, W, b, Y
+            rep.update(_layer_kernel_roofline(L, n, device))
         rep["roofline_integrator"] = integrator_roofline(n, device, dr_stage=args.dr_stage, stats=args.dr_stage > 0)
         # learner alone (no env stepping): back-to-back SAC updates at B = 256 on a fixed batch
         try:
@@ -569,7 +609,7 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
             ob, ep = torch.randn(n, 10, device=device), torch.randn(n, 2, device=device)
             outs = tuple(torch.empty(n, 2, device=device) for _ in range(3))
             us_a = graph_time_us(lambda k: sac.act(ob, ep, out=outs), 5, device)
-            macs = (10 * 256 + 3 * 256 * 256 + 4 * (2 * 256 * 512) + 256 * 512 + 512 * 512 + 512 * 4) if args.family == 0 \
+            macs = (16 * 256 + 3 * 256 * 256 + 4 * (2 * 256 * 512) + 256 * 512 + 512 * 512 + 512 * 4) if args.family == 0 \
                 else (10 * 256 + 256 * 256 + 256 * 4)
             tf_a = 2.0 * macs * n / (us_a * 1e-6) / 1e12
             rep["acting_pass_only"] = {"us_per_call": us_a, "rows": n, "rows_per_s": n / (us_a * 1e-6), "mfma_tflops": tf_a,

@@ -239,6 +239,11 @@ int tvc_sac_set_adam_steps(tvc_sac* sac, const int32_t in[2]);
 int tvc_sac_act(tvc_sac* sac, const float* obs_dev, int32_t n, const float* eps_dev, float* act_dev, float* mean_dev,
                 float* logstd_dev, int32_t flags, void* stream);
 
+/* Diagnostics of the one-launch acting kernel (used for n >= 12 288 rows with the reference shapes): the shader clock the chip
+ * holds inside it (Delta s_memtime / Delta s_memrealtime x 100 MHz, median over workgroups of the last of `launches` back-to-back
+ * launches) -- out[0] = MHz, out[1] = median workgroup lifetime in microseconds, out[2] = workgroups.  Synchronises. */
+int tvc_debug_rows_clock(tvc_sac* sac, const float* obs_dev, int32_t n, int32_t launches, double* out, void* stream);
+
 /* One _update_sac (agent/...:950-1016) on a batch of batch_size rows, in four phases so that the caller can
  * all-reduce gradients between them (data parallel, K10):
  *   critic_grads: target y, q1/q2 forward + backward -> grads[q1|q2], losses[0..1]

@@ -28,4 +28,11 @@ for n in rows:
         best = min(best, e0.elapsed_time(e1) / 5 * 1e3)
     macs = 10 * 256 + 3 * 256 * 256 + 4 * (2 * 256 * 512) + 256 * 512 + 512 * 512 + 512 * 4
     print(f"rows {n:6d}: {best:8.1f} us  {2.0 * macs * n / best / 1e6:6.1f} TFLOP/s  (TVC_ROWS_MIN={os.environ.get('TVC_ROWS_MIN', 'default')})", flush=True)
+    if n >= 12288 or os.environ.get("TVC_ROWS_MIN") == "1":
+        import ctypes as C
+        out = (C.c_double * 3)()
+        rc = sac.L.tvc_debug_rows_clock(sac._h, ob.data_ptr(), n, 40, out, torch.cuda.current_stream().cuda_stream)
+        if rc == 0:
+            print(f"             in-kernel clock {out[0]:7.1f} MHz, median workgroup lifetime {out[1]:8.1f} us, {int(out[2])} workgroups "
+                  f"-> f32-MFMA peak at that clock {out[0] * 1e6 * 64 * 4 * 256 / 1e12:6.1f} TFLOP/s", flush=True)
     sac.close()

@@ -86,7 +86,9 @@ class NativeSAC:
         self.losses = torch.zeros(4, dtype=torch.float32, device=self.device)
         self.n_policy = self.index["q1." + self._critic_first()][0]
         self.n_critic = (n_tr - self.n_policy) // 2
-        self.passive = {}  # reference tensors the SAC path never touches (Q/K projection rows, value head)
+        # reference tensors the SAC path never executes (Q/K projection rows, value head, PE buffer): kept for checkpoints
+        self.passive = ckpt.default_passive(self.cfg.d_model, self.cfg.n_layers, self.cfg.head1, self.cfg.head2, seed) \
+            if self.cfg.family == 0 else {}
         pe = positional_encoding_table(self.cfg.pe_rows, self.cfg.d_model) if self.cfg.family == 0 else None
         self._pe_host = pe
         self._h = C.c_void_p()
@@ -145,8 +147,6 @@ class NativeSAC:
             else:  # kaiming_uniform(a=sqrt 5) == U(-1/sqrt(fan_in), 1/sqrt(fan_in))
                 t.uniform_(-1 / math.sqrt(cols), 1 / math.sqrt(cols), generator=g)
             self.view(name).copy_(t)
-        if self.cfg.family == 0:  # the reference tensors SAC never executes (Q/K projection rows, value head, PE buffer)
-            self.passive = ckpt.default_passive(self.cfg.d_model, self.cfg.n_layers, self.cfg.head1, self.cfg.head2, seed)
         self.sync_targets()
 
     def _is_ln_bias(self, name):

@@ -40,6 +40,7 @@ struct ActRowsArgs {
     float* act; float* mean; float* logstd;      // [M, A]; mean / logstd may be nullptr
     const float4* tiles; const float* vec;       // packed weights
     int M, obs_dim, A, clamp_act, n_layers, n_tiles;
+    unsigned long long* stamps;  // diagnostics (tvc_debug_rows_clock): per workgroup {s_memtime, s_memrealtime} at start and end
 };
 
 struct ArPipe {
@@ -55,39 +56,66 @@ __device__ __forceinline__ void ar_issue_tile(const ArPipe& p, int ti) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 64),
                                          (__attribute__((address_space(3))) void*)(dst + j * 64), 16, 0, 0);
 }
-// make tile p.ti readable, start the copy of tile p.ti + 1 into the other buffer, return the readable tile
+// Make tile p.ti readable, start the copy of tile p.ti + 1 into the buffer that tile p.ti - 1 just vacated, return the readable
+// tile.  __syncthreads() here is: wait for my quarter of tile ti (vmcnt(0): the LDS-DMA is a pending LDS write) and for my
+// fragment reads of tile ti - 1 (lgkmcnt(0)), then s_barrier -- everyone's quarter has landed and everyone is done with the
+// other buffer.  (An inline-asm wait instead hides the counters from hipcc's waitcnt pass, which then answers every later
+// fragment use with a full lgkmcnt(0); three buffers / two tiles ahead measured the same, profiles/r02_c_actor_rows.md.)
 __device__ __forceinline__ const float4* ar_next(ArPipe& p) {
-    // my quarter of tile ti has landed; the barrier says everyone's has, and that everyone is done reading tile ti - 1
-    // (lgkmcnt(0): fragment reads of tile ti - 1 that the compiler issued late have returned before anyone refills their buffer)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __syncthreads();
     const float4* cur = p.Bs + (p.ti & 1) * AR_TILE_F4;
     if (p.ti + 1 < p.n_tiles) ar_issue_tile(p, p.ti + 1);
     p.ti += 1;
     return cur;
 }
-// acc[t] (t = 0..15: output features 16 t + 4 q + r of this lane's row) += W_tile . x_k^T for one 16-deep k-tile
-__device__ __forceinline__ void ar_tile(const float4* __restrict__ cur, const f32x4 xk, f32x4* __restrict__ acc, int l15, int q) {
-    const float4* base = cur + q * 256 + l15;
+// 16 MFMAs of one fragment group: output tiles 4 g .. 4 g + 3 (acc points at the group), the four k-steps of the tile
+__device__ __forceinline__ void ar_mfma16(const float4 (&w)[4], const f32x4 xk, f32x4* __restrict__ acc) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float4 w[4];
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = base[(4 * g + j) * 16];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float wv = c == 0 ? w[j].x : (c == 1 ? w[j].y : (c == 2 ? w[j].z : w[j].w));
-                acc[4 * g + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xk[c], acc[4 * g + j], 0, 0, 0);
-            }
-    }
+        for (int j = 0; j < 4; ++j) {
+            const float wv = c == 0 ? w[j].x : (c == 1 ? w[j].y : (c == 2 ? w[j].z : w[j].w));
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xk[c], acc[j], 0, 0, 0);
+        }
 }
+// the four weight fragments of group g: lane (l15, q) reads image[q][16 (4 g + j) + l15], conflict-free ds_read_b128
+__device__ __forceinline__ void ar_frag4(float4 (&w)[4], const float4* __restrict__ base, int g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = base[(4 * g + j) * 16];
+}
+// order inside one fragment group: 8 MFMAs, the 4 fragment reads of the NEXT group, 8 MFMAs -- the reads are then ~256 cycles old
+// when the next group's first MFMA waits for them (hipcc answers that use with a full lgkmcnt(0), so reads issued right before
+// it would expose an LDS round trip per group)
+#define AR_SCHED_GROUP()                                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);      \
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0)
+// KT k-tiles of one Linear: acc[t] (t = 0..15: output features 16 t + 4 q + r of this lane's row) += W . x^T.
+// The fragment stream is software-pipelined ACROSS tile boundaries with two register sets: the reads of group i + 1 are issued
+// in the middle of the MFMAs of group i, and the tile barrier sits between the loads of a tile's last group and that group's
+// MFMAs, so the first reads of the next tile are in flight while the matrix pipe still works on the previous one.
 template <int KT>
 __device__ __forceinline__ void ar_pass(ArPipe& p, const f32x4* __restrict__ x, f32x4* __restrict__ acc, int l15, int q) {
+    float4 wa[4], wb[4];
+    const float4* base = ar_next(p) + q * 256 + l15;
+    ar_frag4(wa, base, 0);
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-        const float4* cur = ar_next(p);
-        ar_tile(cur, x[kt], acc, l15, q);
+        ar_frag4(wb, base, 1);
+        ar_mfma16(wa, x[kt], acc);
+        AR_SCHED_GROUP();
+        ar_frag4(wa, base, 2);
+        ar_mfma16(wb, x[kt], acc + 4);
+        AR_SCHED_GROUP();
+        ar_frag4(wb, base, 3);
+        ar_mfma16(wa, x[kt], acc + 8);
+        AR_SCHED_GROUP();
+        if (kt + 1 < KT) {
+            base = ar_next(p) + q * 256 + l15;
+            ar_frag4(wa, base, 0);
+        }
+        ar_mfma16(wb, x[kt], acc + 12);
+        AR_SCHED_GROUP();
     }
 }
 __device__ __forceinline__ f32x4 ar_vec4(const float* __restrict__ v, int t, int q) {
@@ -126,6 +154,10 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const int row = blockIdx.x * 64 + wave * 16 + l15;
     const int rowc = min(row, a.M - 1);
+    if (a.stamps && tid == 0) {
+        a.stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime();
+        a.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    }
     ArPipe p{a.tiles, Bs, 0, a.n_tiles, wave, lane};
     ar_issue_tile(p, 0);
 
@@ -140,10 +172,11 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
     const float* vec = a.vec;
     f32x4 x[16];
     // ---- layer 0, first sublayer: embedding + PE(0) + folded attention + residual as ONE obs -> 256 Linear, then norm1
-    {
+    {   // (the stream carries an all-zero second tile behind W': every pass is an even number of tiles, so the fragment
+        //  register sets and the two LDS buffers are in the same phase at every pass boundary)
         ar_zero<16>(x);
-        const float4* cur = ar_next(p);
-        ar_tile(cur, xin, x, l15, q);
+        f32x4 xin2[2] = {xin, xin};
+        ar_pass<2>(p, xin2, x, l15, q);
 #pragma unroll
         for (int t = 0; t < 16; ++t) x[t] += ar_vec4(vec, t, q);
         ar_layernorm<16>(x, vec + 256, vec + 512, q);
@@ -233,6 +266,10 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
     float out[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) out[o] = rstd * (d[o] - mean * gs[o]) + es[o] + tv[5632 + o];
+    if (a.stamps && tid == 0) {
+        a.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+        a.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    }
     // mean, clamped log_std, action = mean + exp(log_std) eps  (agent/...:224-225, 780-782, 789)
     if (q == 0 && row < a.M) {
         for (int j = 0; j < a.A; ++j) {

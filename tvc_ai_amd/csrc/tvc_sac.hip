@@ -9,6 +9,7 @@
 // Layout of this file: net description (Op / NetDef, build_actor / build_critic / derive_infer: the acting net with
 // W_o W_v and the embedding folded) -> executor (net_forward / net_backward: which kernel runs each op, incl. the
 // fused acting launches and the train-mode dropout sites) -> SAC elementwise kernels -> handle + C ABI.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -786,7 +787,7 @@ static bool rows_supported(const tvc_sac_cfg& c, const FoldInfo& f) {
            2 * c.act_dim <= 4 && c.obs_dim <= 16 && f.layers == c.n_layers && c.pe_rows == 1;
 }
 static int rows_min_rows() {  // acting batches at least this large take the one-launch path (64 rows per workgroup)
-    static const int v = [] { const char* e = getenv("TVC_ROWS_MIN"); return e ? atoi(e) : 8192; }();
+    static const int v = [] { const char* e = getenv("TVC_ROWS_MIN"); return e ? atoi(e) : 12288; }();
     return v;
 }
 // Descriptor tables of pack_actor_kernel: the tile stream in the order actor_rows_kernel consumes it, and the vector section.
@@ -807,7 +808,7 @@ static void rows_tables(const tvc_sac_cfg& c, const NetDef& actor, const FoldInf
         const std::string p = "layers." + std::to_string(l) + ".";
         const int lv = l * AR_LAYER_VEC;
         if (l == 0) {
-            pass(f.e_off, f.obs, 0, 0, 1, f.obs, 1);                         // W' [256][obs], one zero-padded 16-deep tile
+            pass(f.e_off, f.obs, 0, 0, 2, f.obs, 1);                         // W' [256][obs]: one zero-padded 16-deep tile + an all-zero one
             vec(f.e_off + (long)d * f.obs, lv, d, 1);                          // b'
         } else {
             pass(l * ostride, d, 0, 0, 16, d, 1);                              // W_ov of layer l
@@ -1066,6 +1067,8 @@ void tvc_sac_destroy(tvc_sac* h) {
     delete h;
 }
 
+static unsigned long long* g_rows_stamps = nullptr;  // set by tvc_debug_rows_clock around its launches
+
 int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float* act, float* mean, float* logstd, int32_t flags,
                 void* stream) {
     if (!h || !obs || !act) return tvc::set_error(TVC_EINVAL, "null argument");
@@ -1082,7 +1085,7 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
         a.obs = obs; a.eps = eps; a.act = act; a.mean = mean; a.logstd = logstd;
         a.tiles = reinterpret_cast<const float4*>(pk); a.vec = pk + (long)h->rows_tiles * 4096;
         a.M = n; a.obs_dim = h->cfg.obs_dim; a.A = A; a.clamp_act = (flags & 1) ? 0 : 1;
-        a.n_layers = h->cfg.n_layers; a.n_tiles = h->rows_tiles;
+        a.n_layers = h->cfg.n_layers; a.n_tiles = h->rows_tiles; a.stamps = g_rows_stamps;
         hipLaunchKernelGGL(actor_rows_kernel, dim3((n + 63) / 64), dim3(256), 0, st, a);
         TVC_HIP_CHECK(hipGetLastError());
         return 0;
@@ -1093,6 +1096,39 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
     hipLaunchKernelGGL(sample_action_kernel, dim3((n * A + 255) / 256), dim3(256), 0, st, head, eps, act, mean, logstd, n, A,
                        (flags & 1) ? 0 : 1);
     TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Diagnostics: in-kernel shader clock of the acting megakernel (guide: DVFS give-back item 6): Delta s_memtime / Delta
+// s_memrealtime x 100 MHz per workgroup, median over workgroups of the last of `launches` back-to-back launches.
+// out[0] = clock MHz, out[1] = median workgroup lifetime in us, out[2] = workgroups.  Synchronises.
+int tvc_debug_rows_clock(tvc_sac* h, const float* obs, int32_t n, int32_t launches, double* out, void* stream) {
+    if (!h || !obs || !out || n < 1 || launches < 1) return tvc::set_error(TVC_EINVAL, "bad argument");
+    if (!h->rows_ok) return tvc::set_error(TVC_EINVAL, "this handle does not use the row-owner acting kernel");
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    const int nwg = (n + 63) / 64, A = h->cfg.act_dim;
+    unsigned long long* st = nullptr;
+    float* act = nullptr;
+    TVC_HIP_CHECK(hipMalloc((void**)&st, (size_t)nwg * 4 * sizeof(unsigned long long)));
+    if (hipMalloc((void**)&act, (size_t)n * A * sizeof(float)) != hipSuccess) { (void)hipFree(st); return tvc::set_error(TVC_ENOMEM, "hipMalloc failed"); }
+    g_rows_stamps = st;
+    int rc = 0;
+    for (int i = 0; i < launches && rc == 0; ++i) rc = tvc_sac_act(h, obs, n, nullptr, act, nullptr, nullptr, 0, stream);
+    g_rows_stamps = nullptr;
+    hipError_t he = hipStreamSynchronize((hipStream_t)stream);
+    std::vector<unsigned long long> v((size_t)nwg * 4);
+    if (rc == 0 && he == hipSuccess) he = hipMemcpy(v.data(), st, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    (void)hipFree(st); (void)hipFree(act);
+    if (rc) return rc;
+    if (he != hipSuccess) return tvc::set_error(TVC_EHIP, "rows clock probe failed: %s", hipGetErrorString(he));
+    std::vector<double> mhz, life;
+    for (int b = 0; b < nwg; ++b) {
+        const double dc = (double)(v[4 * b + 2] - v[4 * b]), dr = (double)(v[4 * b + 3] - v[4 * b + 1]);
+        if (dr > 0) { mhz.push_back(dc / dr * 100.0); life.push_back(dr / 100.0); }
+    }
+    if (mhz.empty()) return tvc::set_error(TVC_EHIP, "no stamps came back");
+    std::sort(mhz.begin(), mhz.end()); std::sort(life.begin(), life.end());
+    out[0] = mhz[mhz.size() / 2]; out[1] = life[life.size() / 2]; out[2] = (double)nwg;
     return 0;
 }
 
