@@ -1,7 +1,9 @@
 """Workload for rocprofv3 --pmc passes.
   pmc_run.py env 8192 65536 4194304   -> eager env_step launches at those sizes
   pmc_run.py gemm 65536 256 256       -> the acting-pass Linear kernel at M N K (tvc_nn_linear_forward)
-  pmc_run.py rowln 65536 256 512      -> the fused Linear + residual + LayerNorm kernel (tvc_nn_linear_ln_forward)"""
+  pmc_run.py rowln 65536 256 512      -> the fused Linear + residual + LayerNorm kernel (tvc_nn_linear_ln_forward)
+  pmc_run.py act 65536                -> the one-launch acting kernel (tvc_sac_act, actor_rows_kernel)
+  pmc_run.py envdr 65536 4194304      -> env_step with full domain randomisation (stage 5) and episode statistics on"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,6 +19,26 @@ if mode == "rowln":  # pmc_run.py rowln M N K -> the fused Linear + residual + L
         nat.check(L.tvc_nn_linear_ln_forward(X.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), g.data_ptr(), be.data_ptr(),
                                              Y.data_ptr(), M, N, K, 0, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
+elif mode == "act":
+    from tvc_ai_amd.agent import NativeSAC, sac_cfg
+    for n in [int(x) for x in sys.argv[2:]]:
+        sac = NativeSAC(sac_cfg(0, batch_size=256, max_act_rows=n), device="cuda:0", seed=2)
+        ob, ep = torch.randn(n, 10, device="cuda"), torch.randn(n, 2, device="cuda")
+        outs = tuple(torch.empty(n, 2, device="cuda") for _ in range(3))
+        for _ in range(10):
+            sac.act(ob, ep, out=outs)
+        torch.cuda.synchronize()
+        sac.close()
+elif mode == "envdr":
+    from tvc_ai_amd import VecRocketTVCEnv
+    from tvc_ai_amd.env import dr_from_yaml
+    for n in [int(x) for x in sys.argv[2:]]:
+        env = VecRocketTVCEnv(n, **dr_from_yaml({}, 5)); env.enable_episode_stats(); env.reset()
+        acts = (torch.rand((4, n, 2), device="cuda") * 2 - 1).contiguous()
+        for k in range(40):
+            env.step(acts[k % 4])
+        torch.cuda.synchronize()
+        env.close()
 elif mode == "gemm":
     from tvc_ai_amd import _native as nat
     L = nat.load()

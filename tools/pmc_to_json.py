@@ -14,7 +14,9 @@ def collect(d, counter):
             if row["Counter_Name"] != counter:
                 continue
             name = re.sub(r"\(anonymous namespace\)::|^void ", "", row["Kernel_Name"]).split("(")[0]
-            if "gemm_rowln" not in name:  # the fused kernel keeps its template arguments: <JT, k-tiles> tell the shapes apart
+            if name.startswith("env_step_kernel<") and name.rstrip().endswith("true>"):
+                name = "env_step_kernel_dr"  # the domain-randomised instantiation <W10, DR = true>
+            elif "gemm_rowln" not in name:  # the fused kernel keeps its template arguments: <JT, k-tiles> tell the shapes apart
                 name = name.split("<")[0]
             acc[(name, int(row["Grid_Size"]))].append(float(row["Counter_Value"]))
     return {k: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in acc.items()}
@@ -24,7 +26,7 @@ fetch = collect(sys.argv[1], "FETCH_SIZE")
 write = collect(sys.argv[2], "WRITE_SIZE")
 out = defaultdict(dict)
 for (name, grid), f in fetch.items():
-    if (name, grid) not in write or not ("env_step" in name or "gemm_kernel" in name or "gemm_rowln" in name):
+    if (name, grid) not in write or not ("env_step" in name or "gemm_kernel" in name or "gemm_rowln" in name or "actor_rows" in name):
         continue
     w = write[(name, grid)]
     out[name][str(grid)] = {"fetch_size_kib_raw": f, "write_size_kib": w, "hbm_read_bytes": f * 1024 * 2,
