@@ -61,6 +61,8 @@ def parse():
                                                                       "acting pass on the second stream)")
     ap.add_argument("--shipped-acting", action="store_true", help="train: act like the reference under its shipped config.yaml "
                                                                   "(hierarchical goal policy + safety layer + curiosity bonus)")
+    ap.add_argument("--share-cus", choices=["auto", "on", "off"], default="auto",
+                    help="train: one acting workgroup per CU so that the update runs beside the acting pass (auto: on with the two-stream schedule)")
     ap.add_argument("--no-overlap", action="store_true", help="train: run the update after the acting pass instead of beside it")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per K steps")
     ap.add_argument("--graph", action="store_true", help="train: capture the K steps in one hipGraph (default: eager; the host "

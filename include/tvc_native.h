@@ -234,7 +234,9 @@ int tvc_sac_set_adam_steps(tvc_sac* sac, const int32_t in[2]);
 
 /* Policy part of get_action (agent/...:765-789) for n rows: mean/log_std (clamped to [-20,2]) and
  * action = clamp(mean + exp(log_std) * eps, -1, 1); eps_dev NULL = deterministic (action = clamp(mean)).
- * flags bit 0: do not clamp (the safety layer sees the raw sample, agent/...:780-789); bit 1: act with the snapshot.
+ * flags bit 0: do not clamp (the safety layer sees the raw sample, agent/...:780-789); bit 1: act with the snapshot;
+ * bit 2: share the CUs -- the one-launch acting kernel (n >= 12 288 rows, reference shapes) then occupies half of each CU's
+ * registers instead of all of them, so that kernels on other streams (a SAC update) run beside it instead of after it.
  * obs_dev float[n,obs]; act_dev float[n,A]; mean_dev / logstd_dev float[n,A] or NULL. */
 int tvc_sac_act(tvc_sac* sac, const float* obs_dev, int32_t n, const float* eps_dev, float* act_dev, float* mean_dev,
                 float* logstd_dev, int32_t flags, void* stream);

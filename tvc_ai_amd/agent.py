@@ -222,16 +222,18 @@ class NativeSAC:
         """copy the policy into the acting snapshot (read by act(..., snapshot=True)) on the current stream"""
         nat.check(self.L.tvc_sac_snapshot_policy(self._h, self._stream()))
 
-    def act(self, obs: torch.Tensor, eps: Optional[torch.Tensor] = None, out=None, clamp: bool = True, snapshot: bool = False):
+    def act(self, obs: torch.Tensor, eps: Optional[torch.Tensor] = None, out=None, clamp: bool = True, snapshot: bool = False,
+            share_cus: bool = False):
         """-> (action[n,A] clamped to [-1,1] unless clamp=False, mean, log_std); eps None = deterministic.
-        snapshot=True acts with the parameters of the last snapshot_policy() instead of the live ones."""
+        snapshot=True acts with the parameters of the last snapshot_policy() instead of the live ones; share_cus=True leaves
+        half of every CU to other streams (tvc_sac_act flags bit 2)."""
         n, A = obs.shape[0], self.cfg.act_dim
         assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.cfg.obs_dim
         if out is None:
             out = tuple(torch.empty((n, A), dtype=torch.float32, device=self.device) for _ in range(3))
         act, mean, ls = out
         nat.check(self.L.tvc_sac_act(self._h, obs.data_ptr(), n, nat.ptr(eps), act.data_ptr(), mean.data_ptr(), ls.data_ptr(),
-                                     (0 if clamp else 1) | (2 if snapshot else 0), self._stream()))
+                                     (0 if clamp else 1) | (2 if snapshot else 0) | (4 if share_cus else 0), self._stream()))
         return act, mean, ls
 
     def update(self, s, a, r, s2, d, eps_next, eps_new, all_reduce=None, grad_scale: float = 1.0):

@@ -1086,7 +1086,21 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
         a.tiles = reinterpret_cast<const float4*>(pk); a.vec = pk + (long)h->rows_tiles * 4096;
         a.M = n; a.obs_dim = h->cfg.obs_dim; a.A = A; a.clamp_act = (flags & 1) ? 0 : 1;
         a.n_layers = h->cfg.n_layers; a.n_tiles = h->rows_tiles; a.stamps = g_rows_stamps;
-        hipLaunchKernelGGL(actor_rows_kernel, dim3((n + 63) / 64), dim3(256), 0, st, a);
+        // flags bit 2 ("share the CUs"): 64 KB of unused dynamic LDS make the kernel fit once per CU instead of twice, which
+        // leaves half of every CU's registers (and 64 KB of LDS) to whatever runs on other streams -- the ~100 small kernels of
+        // a SAC update beside the acting pass.  Two workgroups per CU own every VGPR of the CU: faster alone (1.9 vs 2.4 ms at
+        // 65 536 rows), but nothing else can then run until they retire.
+        size_t dyn_lds = 0;
+        if (flags & 4) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                TVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(actor_rows_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+                attr_set = true;
+            }
+            dyn_lds = 65536;
+        }
+        hipLaunchKernelGGL(actor_rows_kernel, dim3((n + 63) / 64), dim3(256), dyn_lds, st, a);
         TVC_HIP_CHECK(hipGetLastError());
         return 0;
     }

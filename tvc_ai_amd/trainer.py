@@ -22,7 +22,8 @@ class VecTrainer:
     def __init__(self, num_envs: int, device="cuda:0", config: Optional[dict] = None, family: int = 0, batch_size: int = 256,
                  replay_capacity: int = 1_000_000, seed: int = 42, rank: int = 0, world: int = 1, updates_per_step: int = 1,
                  max_episode_steps: int = 1000, enable_curiosity: bool = False, overlap: bool = True,
-                 enable_hierarchical: bool = False, enable_safety: bool = False, dropout_p: Optional[float] = None, **env_over):
+                 enable_hierarchical: bool = False, enable_safety: bool = False, dropout_p: Optional[float] = None,
+                 share_cus: Optional[bool] = None, **env_over):
         self.device = torch.device(device)
         self.n, self.B, self.world, self.rank = num_envs, batch_size, world, rank
         self.updates_per_step = updates_per_step
@@ -37,6 +38,11 @@ class VecTrainer:
         self.rb = ReplayBuffer(replay_capacity, 10, 2, device=self.device, seed=seed * 1000003 + rank)
         self.sync = GradSync() if world > 1 else None
         self.overlap = overlap
+        # acting kernel placement (tvc_sac_act flags bit 2): alone on the chip it is fastest with two workgroups per CU, which
+        # own every register of the CU -- the update then runs AFTER the acting pass.  One workgroup per CU is ~25 % slower
+        # alone but lets the update's kernels run BESIDE it, which wins at every update count (65 536 envs: 2.49 vs 2.58 ms per
+        # step at 1 update per step, 2.74 vs 3.40 at 2, 4.18 vs 4.92 at 4; profiles/r02_f_bench_matrix.md).
+        self.share_cus = bool(overlap) if share_cus is None else bool(share_cus)
         self._side = torch.cuda.Stream(self.device)
         self._fork = torch.cuda.Event()
         # intrinsic curiosity bonus of the reference's training env (scripts/train.py:318, env/...:496-502)
@@ -133,7 +139,8 @@ class VecTrainer:
             a, _, _, _ = self.hier.act(cur, self.eps_act, self.u_goal, clamp=self.safety is None)
             raw.copy_(a)
         else:
-            self.sac.act(cur, self.eps_act, out=(raw, self.mean, self.ls), clamp=self.safety is None, snapshot=self._snapshot)
+            self.sac.act(cur, self.eps_act, out=(raw, self.mean, self.ls), clamp=self.safety is None, snapshot=self._snapshot,
+                         share_cus=self.share_cus and self._snapshot)
         if self.safety is not None:  # sees the unclamped sample; clamps its result
             self.safety.apply(cur, raw, out=self.act)
         o, rew, term, trunc, info = self.env.step(self.act, out_obs=nxt)
@@ -270,6 +277,7 @@ def bench_train(args, world, rank, device, n_envs=None):
     utd = max(1, int(getattr(args, "updates_per_step", 1)))
     tr = VecTrainer(n, device=device, family=family, batch_size=256, replay_capacity=1_000_000, seed=42,
                     rank=rank, world=world, updates_per_step=utd, overlap=not getattr(args, "no_overlap", False),
+                    share_cus={"auto": None, "on": True, "off": False}[getattr(args, "share_cus", "auto")],
                     enable_hierarchical=shipped, enable_safety=shipped, enable_curiosity=shipped, **env_over)
     if stage is not None:  # the curriculum driver reads device-side episode statistics and owns the stage from here on
         from .curriculum import CurriculumDriver
@@ -284,6 +292,7 @@ def bench_train(args, world, rank, device, n_envs=None):
             "extra": {"updates_per_step": float(utd), "sac": {"family": fam, "batch": 256, "replay_capacity": 1_000_000,
                                                       "utd": f"{utd} update(s) per vector step", "dtype": "f32 MFMA",
                                                       "dropout_in_update": tr.dropout_p,
+                                                      "acting_kernel_shares_cus": tr.share_cus,
                                                       "acting": "hierarchical goal policy + safety layer + curiosity bonus (shipped config.yaml)"
                                                       if shipped else "SAC policy",
                                                       "domain_randomisation": "off (shipped env)" if stage is None
