@@ -642,21 +642,27 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
             ag = MultiAlgorithmAgent(10, 2, {"tvc_native": {"batch_size": 1, "max_act_rows": 16},
                                              "physics_informed": {"enabled": True}, "hierarchical_rl": {"enabled": True},
                                              "safety": {"safety_layer": {"enabled": True}}}, device=device)
-            obs, _ = env1.reset()
-            n1 = 0
-            t0 = time.perf_counter()
-            while n1 < 300 and time.perf_counter() - t0 < 10.0:
-                a, _ = ag.get_action(torch.from_numpy(obs).unsqueeze(0))
-                nobs, r, term, trunc, _ = env1.step(a.flatten())
-                ag.update({"states": torch.from_numpy(obs).unsqueeze(0), "actions": torch.from_numpy(a),
-                           "rewards": torch.tensor([r]), "next_states": torch.from_numpy(nobs).unsqueeze(0),
-                           "dones": torch.BoolTensor([term or trunc])})
-                obs = env1.reset()[0] if (term or trunc) else nobs
-                n1 += 1
-            rep["reference_plumbing_n1"] = {"steps_per_s": n1 / (time.perf_counter() - t0), "steps": n1,
+            def loop(algorithm, budget):
+                obs, _ = env1.reset()
+                n1 = 0
+                t0 = time.perf_counter()
+                while n1 < 200 and time.perf_counter() - t0 < budget:
+                    a, _ = ag.get_action(torch.from_numpy(obs).unsqueeze(0), algorithm=algorithm)
+                    nobs, r, term, trunc, _ = env1.step(a.flatten())
+                    ag.update({"states": torch.from_numpy(obs).unsqueeze(0), "actions": torch.from_numpy(a),
+                               "rewards": torch.tensor([r]), "next_states": torch.from_numpy(nobs).unsqueeze(0),
+                               "dones": torch.BoolTensor([term or trunc])}, algorithm=algorithm)
+                    obs = env1.reset()[0] if (term or trunc) else nobs
+                    n1 += 1
+                return n1 / (time.perf_counter() - t0), n1
+            sps_ref, n_ref = loop(None, 6.0)   # what scripts/train.py does: select_algorithm() -> 'ppo' (eager pass-through update)
+            sps_sac, n_sac = loop("sac", 6.0)  # the same loop pinned to the accelerated learner
+            rep["reference_plumbing_n1"] = {"steps_per_s": sps_sac, "steps": n_sac, "steps_per_s_default_selection_ppo_passthrough": sps_ref,
                                             "config": "config.yaml defaults: hierarchical goal policy + safety layer + curiosity + physics-informed loss on",
-                                            "note": "1 env + 1 online SAC update per step through the reference's Python surface "
-                                                    "(host round trips every call); reference docs imply 35-93 steps/s (BASELINE.md)"}
+                                            "note": "1 env + 1 online update per step through the reference's Python surface (host round "
+                                                    "trips every call); steps_per_s = algorithm 'sac' (HIP learner), the other figure = the "
+                                                    "reference's own default selection, 'ppo', through the eager pass-through; reference "
+                                                    "docs imply 35-93 steps/s (BASELINE.md)"}
             env1.close()
         except Exception as e:
             rep["reference_plumbing_n1"] = {"error": str(e)}

@@ -46,5 +46,7 @@ def test_agent_get_action_with_safety_layer_enabled():
     cfg = {"tvc_native": {"batch_size": 1, "max_act_rows": 64}, "safety": {"safety_layer": {"enabled": True}}}
     agent = MultiAlgorithmAgent(10, 2, cfg)
     obs = torch.randn(32, 10)
-    a, info = agent.get_action(obs)
+    a, info = agent.get_action(obs, algorithm="sac")
     assert a.shape == (32, 2) and np.all(np.abs(a) <= 1.0) and info["algorithm"] == "sac"
+    a, info = agent.get_action(obs)  # the reference's default choice is 'ppo' (eager pass-through); same safety layer after it
+    assert a.shape == (32, 2) and np.all(np.abs(a) <= 1.0) and info["algorithm"] == "ppo"

@@ -157,3 +157,43 @@ def test_reference_load_checkpoint_reads_a_file_packed_here_and_back(tmp_path, m
     steps, _, have = ck.unpack_sac(lay, c["algorithms"]["sac"], p2, m2, v2)
     assert have and steps == [9, 8]
     assert same_tensors(lay, p2, params) and same_tensors(lay, m2, m, True) and same_tensors(lay, v2, v, True)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference tree (build container only)")
+def test_passthrough_nets_are_the_references_nets():
+    """The eager PPO / TD3 pass-through (tvc_ai_amd/passthrough.py) against the reference's own modules: identical state_dict
+    keys and shapes (strict load both ways) and identical forward outputs in eval mode on the same weights, batch-row
+    positional encoding included."""
+    import yaml
+    from tvc_ai_amd import passthrough as pt
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    try:
+        from agent.multi_algorithm_agent import MultiAlgorithmAgent as RefAgent
+    finally:
+        sys.path.remove(REF)
+    cfg = yaml.safe_load(open(os.path.join(REF, "config", "config.yaml")))
+    cfg["hardware"] = {"device": "cpu"}
+    ref = RefAgent(10, 2, cfg)
+    mine = pt.make_ppo(10, 2, cfg, torch.device("cpu"))
+    ref_pol = ref.algorithms["ppo"]["policy"]
+    ref_pol.load_state_dict(mine["policy"].state_dict())            # strict
+    mine["policy"].load_state_dict(ref_pol.state_dict())
+    ref_pol.eval(); mine["policy"].eval()
+    x = torch.randn(7, 10)
+    with torch.no_grad():
+        for a, b in zip(ref_pol(x), mine["policy"](x)):
+            assert torch.allclose(a, b, atol=1e-6), (a - b).abs().max()
+    assert mine["optimizer"].param_groups[0]["lr"] == ref.algorithms["ppo"]["optimizer"].param_groups[0]["lr"] == 2.5e-4
+    td = pt.make_td3(10, 2, torch.device("cpu"))
+    for k in ("policy", "q1", "q2", "target_policy", "target_q1", "target_q2"):
+        ref.algorithms["td3"][k].load_state_dict(td[k].state_dict())  # strict
+    ref.algorithms["td3"]["policy"].eval(); td["policy"].eval()
+    with torch.no_grad():
+        assert torch.allclose(ref.algorithms["td3"]["policy"](x), td["policy"](x), atol=1e-6)
+    # one PPO update on the same batch from the same weights gives the same losses (dropout off on both sides)
+    batch = {"states": x, "actions": torch.rand(7, 2) * 2 - 1, "rewards": torch.randn(7), "next_states": x + 0.1, "dones": torch.zeros(7)}
+    lr_ = ref._update_ppo(batch)
+    lm = pt.update_ppo(mine, batch)
+    for k in lr_:
+        assert abs(lr_[k] - lm[k]) <= 1e-5 * max(1.0, abs(lr_[k])), (k, lr_[k], lm[k])

@@ -258,17 +258,53 @@ def test_agent_surface_update_accepts_bool_dones():
     """MultiAlgorithmAgent drop-in: scripts/train.py:577-584 builds B=1 tensors with a BoolTensor `dones`."""
     from tvc_ai_amd.agent import MultiAlgorithmAgent
     agent = MultiAlgorithmAgent(10, 2, {"tvc_native": {"batch_size": 1, "max_act_rows": 16}, "physics_informed": {"enabled": True}})
+    assert list(agent.algorithms) == ["ppo", "sac", "td3"]  # the reference builds all three by default (:487-497)
     obs = torch.randn(1, 10)
-    action, info = agent.get_action(obs)
+    action, info = agent.get_action(obs, algorithm="sac")
     assert isinstance(action, np.ndarray) and action.shape == (1, 2) and np.all(np.abs(action) <= 1)
     assert info["algorithm"] == "sac" and info["mean"].shape == (1, 2)
     batch = {"states": obs, "actions": torch.from_numpy(action), "rewards": torch.tensor([1.5]),
              "next_states": obs + 0.1, "dones": torch.BoolTensor([False])}
-    out = agent.update(batch)
+    out = agent.update(batch, algorithm="sac")
     assert set(out) >= {"q1_loss", "q2_loss", "policy_loss"} and all(np.isfinite(v) for v in out.values()), out
-    assert agent.select_algorithm() == "sac"
     agent.update_performance("sac", 12.0)
     assert list(agent.performance_history["sac"]) == [12.0]
+    assert agent.select_algorithm() == "sac"  # the only algorithm with a history (:700-706)
+
+
+def test_select_algorithm_and_the_eager_passthrough_follow_the_reference():
+    """agent/...:693-709, 736-809, 868-948, 1018-1086: with no history the 'dynamic' strategy answers 'ppo' (so the reference's
+    own loop, scripts/train.py:544-584, acts and updates through PPO); PPO / TD3 are the eager-PyTorch pass-through here; the
+    'voting' strategy acts with the weighted ensemble of all three policies, the SAC one through the HIP kernels."""
+    from tvc_ai_amd.agent import MultiAlgorithmAgent
+    cfg = {"tvc_native": {"batch_size": 8, "max_act_rows": 16}}
+    agent = MultiAlgorithmAgent(10, 2, cfg, seed=3)
+    assert agent.select_algorithm() == "ppo"
+    obs = torch.randn(8, 10)
+    act, info = agent.get_action(obs)
+    assert info["algorithm"] == "ppo" and act.shape == (8, 2) and np.all(np.abs(act) <= 1)
+    batch = {"states": obs, "actions": torch.from_numpy(act), "rewards": torch.randn(8), "next_states": obs + 0.1,
+             "dones": torch.BoolTensor([False] * 8)}
+    p0 = [p.detach().clone() for p in agent.algorithms["ppo"]["policy"].parameters()]
+    out = agent.update(batch)  # algorithm None -> select_algorithm() -> 'ppo'
+    assert set(out) == {"policy_loss", "value_loss", "total_loss"} and all(np.isfinite(v) for v in out.values())
+    assert any(not torch.equal(a, b) for a, b in zip(p0, agent.algorithms["ppo"]["policy"].parameters()))
+    t1 = agent.update(batch, algorithm="td3")
+    t2 = agent.update(batch, algorithm="td3")
+    assert t1["policy_loss"] == 0.0 and t2["policy_loss"] != 0.0  # delayed policy update: every second call (:1060-1066)
+    a3, i3 = agent.get_action(obs, algorithm="td3", deterministic=True)
+    assert np.all(np.abs(a3) <= 1) and np.all(i3["log_std"] == 0)
+    for _ in range(3):
+        agent.update_performance("td3", 5.0)
+    agent.update_performance("sac", 9.0)
+    assert agent.select_algorithm() == "sac"
+    agent.selection_strategy = "voting"
+    ae, ie = agent.get_action(obs)
+    assert ie["algorithm"] == "ensemble" and len(ie["individual_actions"]) == 3 and abs(float(ie["weights"].sum()) - 1) < 1e-6
+    # passthrough off: 'ppo' is still what the rule answers, get_action falls back to the first available algorithm (:757-759)
+    only = MultiAlgorithmAgent(10, 2, {"tvc_native": {"batch_size": 8, "max_act_rows": 16, "passthrough": False}}, seed=3)
+    assert list(only.algorithms) == ["sac"] and only.select_algorithm() == "ppo"
+    assert only.get_action(obs)[1]["algorithm"] == "sac" and only.update(batch) == {}
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 512, 256), (300, 200, 37), (8192, 256, 256), (64, 12, 512), (1000, 256, 12)])
@@ -311,12 +347,16 @@ def test_checkpoint_layout_and_round_trip(tmp_path):
                   "rewards": torch.randn(32, generator=g), "next_states": torch.randn(32, 10, generator=g),
                   "dones": torch.rand(32, generator=g) < 0.1}
     for _ in range(3):
-        assert "error" not in a.update(mk())
+        assert "error" not in a.update(mk(), algorithm="sac")
+    assert "error" not in a.update(mk(), algorithm="ppo")  # the eager pass-through entries travel in the same file
     a.update_performance("sac", np.float64(12.5))  # numpy scalars end up in the deques (scripts/train.py:606)
     path = str(tmp_path / "ckpt.pth")
     a.save_checkpoint(path)
     ck = ckpt.load_file(path)
-    assert list(ck.keys()) == man["top_level_keys"]
+    assert list(ck.keys()) == man["top_level_keys"] and list(ck["algorithms"]) == man["algorithms"] == ["ppo", "sac", "td3"]
+    assert set(ck["algorithms"]["ppo"]) == {"policy_state", "optimizer_state", "type"}
+    assert [[k, list(t.shape)] for k, t in ck["algorithms"]["ppo"]["policy_state"].items()] == \
+        [[k, sh] for k, sh, _ in man["nets"]["policy"]["state_dict"]]  # PPO's net is the same TransformerPolicyNetwork
     assert isinstance(ck["performance_history"]["sac"], collections.deque) and ck["performance_history"]["sac"].maxlen == 100
     sac = ck["algorithms"]["sac"]
     assert list(sac.keys()) == man["sac_keys"] and sac["type"] == "sac"
@@ -337,8 +377,8 @@ def test_checkpoint_layout_and_round_trip(tmp_path):
     b = MultiAlgorithmAgent(10, 2, cfg, seed=99)
     b.load_checkpoint(path)
     obs = torch.randn(16, 10)
-    act_a, _ = a.get_action(obs, deterministic=True)
-    act_b, _ = b.get_action(obs, deterministic=True)
+    act_a, _ = a.get_action(obs, deterministic=True, algorithm="sac")
+    act_b, _ = b.get_action(obs, deterministic=True, algorithm="sac")
     np.testing.assert_allclose(act_a, act_b, atol=1e-6)
     lay = a.sac.layout
     for name, off, rows, cols in lay.table:
@@ -349,7 +389,9 @@ def test_checkpoint_layout_and_round_trip(tmp_path):
     assert b.sac.adam_steps() == [3, 3] and list(b.performance_history["sac"]) == [12.5]
     # the next update of both agents is the same update
     batch = mk()
-    la, lb = a.update(batch), b.update(batch)
+    la, lb = a.update(batch, algorithm="sac"), b.update(batch, algorithm="sac")
+    for pa, pb in zip(a.algorithms["ppo"]["policy"].parameters(), b.algorithms["ppo"]["policy"].parameters()):
+        assert torch.equal(pa, pb)
     assert "error" not in la and set(la) == set(lb)
     # a reference-written file holds PPO / TD3 entries and a value head with its own weights: they survive a load + save
     sac2 = dict(sac)

@@ -215,14 +215,16 @@ def test_run_episode_shaped_loop_through_the_dropin_module_paths():
             batch = {"states": torch.FloatTensor(obs).unsqueeze(0).cuda(), "actions": torch.FloatTensor(action).unsqueeze(0).cuda(),
                      "rewards": torch.FloatTensor([reward]).cuda(), "next_states": torch.FloatTensor(next_obs).unsqueeze(0).cuda(),
                      "dones": torch.BoolTensor([terminated or truncated]).cuda()}
-            losses = agent.update(batch, algorithm="sac")
+            losses = agent.update(batch)  # like scripts/train.py:584: the algorithm select_algorithm() answers ('ppo' at first)
             assert "error" not in losses and all(np.isfinite(v) for v in losses.values()), losses
+            sac_losses = agent.update(batch, algorithm="sac")  # and the accelerated learner on the same B = 1 batch
+            assert {"q1_loss", "q2_loss", "policy_loss"} <= set(sac_losses), sac_losses
             episode_reward += reward
             total_timesteps += 1
             if terminated or truncated:
                 break
             obs = next_obs
         agent.update_performance(algorithm, episode_reward)
-    assert total_timesteps > 30 and {"q1_loss", "q2_loss", "policy_loss"} <= set(losses)
+    assert total_timesteps > 30 and {"policy_loss", "value_loss", "total_loss"} == set(losses) and algorithm == "ppo"
     assert len(agent.performance_history[algorithm]) == 3
     env.close()

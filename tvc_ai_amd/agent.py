@@ -341,17 +341,32 @@ class ReplayBuffer:
         return out
 
 
-class MultiAlgorithmAgent:
-    """Drop-in for the reference class of the same name (agent/multi_algorithm_agent.py:419) on the SAC path.
+def _physics_loss_eager(s, a, s2, weight):
+    """PhysicsInformedLoss.forward (agent/...:236-285) for the eager pass-through algorithms (the HIP update computes it itself)"""
+    w, w2 = s[:, 4:7], s2[:, 4:7]
+    an = torch.norm(a, dim=-1, keepdim=True)
+    mom = torch.mean((w2 - (w + an * 0.1)) ** 2)
+    en = torch.mean((0.5 * (w2 ** 2).sum(-1) - (0.5 * (w ** 2).sum(-1) + 0.5 * (a ** 2).sum(-1) * 0.01)) ** 2)
+    qn = torch.mean((torch.norm(s[:, :4], dim=-1) - 1.0) ** 2) + torch.mean((torch.norm(s2[:, :4], dim=-1) - 1.0) ** 2)
+    return weight * (mom + en + qn)
 
-    Same constructor ``(obs_dim, action_dim, config)`` and methods ``select_algorithm``, ``get_action``,
-    ``update``, ``update_performance``, ``save_checkpoint``, ``load_checkpoint``, ``to``; attributes
-    ``performance_history``, ``algorithms``, ``device``.  PPO / TD3 / ensemble paths are out of scope (SURVEY
-    section 2): ``select_algorithm`` answers 'sac'.  With ``hierarchical_rl.enabled`` (true in the shipped
-    config.yaml:103-104) ``get_action`` follows the reference (:751-754) and acts with the never-trained goal policy +
-    goal-conditioned low-level policy of ``hierarchical.HierarchicalPolicy`` instead of the SAC policy; set it to false
-    to act with the policy that ``update`` trains.  Deliberate fix: ``update`` accepts
-    the BoolTensor ``dones`` that scripts/train.py:582 builds (the reference raises on it and skips the update).
+
+class MultiAlgorithmAgent:
+    """Drop-in for the reference class of the same name (agent/multi_algorithm_agent.py:419).
+
+    Same constructor ``(obs_dim, action_dim, config)`` and methods ``select_algorithm``, ``get_action``, ``update``,
+    ``update_performance``, ``save_checkpoint``, ``load_checkpoint``, ``to``; attributes ``performance_history``,
+    ``algorithms``, ``algorithm_weights``, ``device``.
+
+    * 'sac' is the MI355X-native learner (``NativeSAC``: HIP kernels end to end).
+    * 'ppo' and 'td3' are an eager-PyTorch PASS-THROUGH (``passthrough.py``, not accelerated), present when
+      ``algorithms.<name>.enabled`` (default true, like the reference :487-497) so that ``select_algorithm`` follows the
+      reference rule (:693-709) -- which, like the reference, answers 'ppo' until another algorithm has a performance history.
+      ``tvc_native.passthrough: false`` leaves them out.
+    * With ``hierarchical_rl.enabled`` (true in the shipped config.yaml:103-104) ``get_action`` follows the reference (:751-754)
+      and acts with the never-trained goal policy + goal-conditioned low-level policy of ``hierarchical.HierarchicalPolicy``.
+    Deliberate fix: ``update`` accepts the BoolTensor ``dones`` that scripts/train.py:582 builds (the reference
+    raises on it inside _update_sac / _update_td3 and skips the update).
     """
 
     def __init__(self, obs_dim: int, action_dim: int, config: dict, device=None, seed: int = 42):
@@ -364,21 +379,39 @@ class MultiAlgorithmAgent:
         hd = (net.get("mlp_backbone", {}) or {}).get("hidden_dims", [512, 512, 256])
         family = int(native.get("family", 0))
         self.batch_size = int(native.get("batch_size", 1))
-        cfg = sac_cfg(family, obs_dim=obs_dim, act_dim=action_dim, d_model=int(tr.get("d_model", 256)),
-                      n_layers=int(tr.get("num_layers", 4)), ff_dim=int(tr.get("dim_feedforward", 512)),
-                      head1=int(hd[0]), head2=int(hd[1]), batch_size=self.batch_size,
-                      max_act_rows=int(native.get("max_act_rows", 4096)), pe_rows=int(native.get("pe_rows", 1)),
-                      nhead=int(tr.get("nhead", 8)),
-                      # the reference never calls .eval(): its update runs with Dropout active (network.transformer.dropout for
-                      # the policy, a hard-coded 0.1 in the critics, agent/...:457,596-604); one value drives both here
-                      dropout_p=float(native.get("dropout", tr.get("dropout", 0.1))) if family == 0 else 0.0)
-        self.sac = NativeSAC(cfg, device=self.device, seed=seed)
-        self.algorithms = {"sac": {"type": "sac", "native": self.sac}}
-        self.algorithm_weights = {"sac": 1.0}
+        algs = self.config.get("algorithms", {}) or {}
+        enabled = lambda a: bool((algs.get(a, {}) or {}).get("enabled", True))
+        passthrough_on = bool(native.get("passthrough", True))
+        self.algorithms = {}
+        self.algorithm_weights = {}
+        # construction order of the reference (:487-497): ppo, sac, td3 -- it decides the "first available" fallback (:757-759)
+        if enabled("ppo") and passthrough_on:
+            from . import passthrough
+            torch.manual_seed(seed + 101)
+            self.algorithms["ppo"] = passthrough.make_ppo(obs_dim, action_dim, self.config, self.device)
+            self.algorithm_weights["ppo"] = 1.0
+        if enabled("sac"):
+            cfg = sac_cfg(family, obs_dim=obs_dim, act_dim=action_dim, d_model=int(tr.get("d_model", 256)),
+                          n_layers=int(tr.get("num_layers", 4)), ff_dim=int(tr.get("dim_feedforward", 512)),
+                          head1=int(hd[0]), head2=int(hd[1]), batch_size=self.batch_size,
+                          max_act_rows=int(native.get("max_act_rows", 4096)), pe_rows=int(native.get("pe_rows", 1)),
+                          nhead=int(tr.get("nhead", 8)),
+                          # the reference never calls .eval(): its update runs with Dropout active (network.transformer.dropout
+                          # for the policy, a hard-coded 0.1 in the critics, agent/...:457,596-604); one value drives both here
+                          dropout_p=float(native.get("dropout", tr.get("dropout", 0.1))) if family == 0 else 0.0)
+            self.sac = NativeSAC(cfg, device=self.device, seed=seed)
+            self.algorithms["sac"] = {"type": "sac", "native": self.sac}
+            self.algorithm_weights["sac"] = 1.0
+        else:
+            self.sac = None
+        if enabled("td3") and passthrough_on:
+            from . import passthrough
+            torch.manual_seed(seed + 103)
+            self.algorithms["td3"] = passthrough.make_td3(obs_dim, action_dim, self.device)
+            self.algorithm_weights["td3"] = 1.0
         self.performance_history = {alg: deque(maxlen=100) for alg in ["ppo", "sac", "td3"]}
-        self.selection_strategy = (self.config.get("algorithms", {}).get("ensemble", {}) or {}).get("selection_strategy", "dynamic")
+        self.selection_strategy = (algs.get("ensemble", {}) or {}).get("selection_strategy", "dynamic")
         self._gen = torch.Generator(device=self.device).manual_seed(seed)
-        self._current_algorithm = "sac"
         # SafetyLayer (agent/...:515-520): an untrained correction net + constraint test, applied when enabled
         self.safety_layer = None
         saf = self.config.get("safety", {}) or {}
@@ -397,30 +430,77 @@ class MultiAlgorithmAgent:
                                                          max_rows=int(native.get("max_act_rows", 4096)), seed=seed)
 
     def to(self, device):
-        if torch.device(device) != self.device:
+        if torch.device(device).type != self.device.type:
             self.logger.warning("MultiAlgorithmAgent(native) stays on %s (requested %s)", self.device, device)
         return self
 
     def select_algorithm(self, performance_metrics: Optional[Dict] = None):
-        self._current_algorithm = "sac"
-        return "sac"
+        """the reference rule, agent/...:693-709: 'dynamic' = best mean of the last 10 performances among the algorithms that
+        HAVE a history, else 'ppo'; 'voting' = 'ensemble'; otherwise best mean over the whole history, else 'ppo'"""
+        previous = getattr(self, "_current_algorithm", None)
+        if self.selection_strategy == "voting":
+            selected = "ensemble"
+        else:
+            last = 10 if self.selection_strategy == "dynamic" else None
+            best, best_perf = None, -float("inf")
+            for name, hist in self.performance_history.items():
+                if len(hist) > 0 and name in self.algorithms:
+                    vals = list(hist)[-last:] if last else list(hist)
+                    perf = float(np.mean(vals))
+                    if perf > best_perf:
+                        best, best_perf = name, perf
+            selected = best or "ppo"
+        if previous is not None and previous != selected:
+            self.logger.info(f"Algorithm switch: {previous} -> {selected}")
+        self._current_algorithm = selected
+        return selected
+
+    def _policy_action(self, name: str, state: torch.Tensor, deterministic: bool, clamp: bool):
+        """(action, mean, log_std) of one algorithm's policy: HIP kernels for 'sac', eager torch for the pass-through nets"""
+        agent = self.algorithms[name]
+        if agent["type"] == "sac":
+            eps = None if deterministic else torch.randn((state.shape[0], self.action_dim), device=self.device, generator=self._gen)
+            return self.sac.act(state, eps, clamp=clamp)
+        from . import passthrough
+        with torch.no_grad():
+            mean, log_std, _ = passthrough.policy_outputs(agent, state)
+            act = passthrough.sample(agent, mean, log_std, deterministic)
+        return (torch.clamp(act, -1.0, 1.0) if clamp else act), mean, log_std
 
     def get_action(self, state: torch.Tensor, deterministic: bool = False, algorithm: Optional[str] = None):
-        """-> (np.ndarray[B, A], info) like agent/...:736-809 (SAC policy, clamp to [-1,1])."""
+        """-> (np.ndarray[B, A], info) like agent/...:736-809."""
         try:
+            if algorithm is None:
+                algorithm = self.select_algorithm()
             state = torch.as_tensor(state, dtype=torch.float32, device=self.device)
             if state.dim() == 1:
                 state = state.unsqueeze(0)
             state = state.contiguous()
-            eps = None if deterministic else torch.randn((state.shape[0], self.action_dim), device=self.device, generator=self._gen)
+            raw = self.safety_layer is not None  # the safety layer sees the unclamped sample (agent/...:785-789)
+            if algorithm == "ensemble":  # agent/...:811-866: weighted mean of every algorithm's action
+                acts, weights = [], []
+                for name in self.algorithms:
+                    a, _, _ = self._policy_action(name, state, deterministic, clamp=False)
+                    acts.append(a)
+                    weights.append(self.algorithm_weights.get(name, 1.0))
+                w = torch.tensor(weights, device=self.device)
+                w = w / w.sum()
+                act = sum(wi * ai for wi, ai in zip(w, acts))
+                act = self.safety_layer.apply(state, act.contiguous()) if raw else torch.clamp(act, -1.0, 1.0)
+                return act.cpu().numpy(), {"algorithm": "ensemble", "weights": w.cpu().numpy(),
+                                           "individual_actions": [a.cpu().numpy() for a in acts]}
             goal = None
             if self.hierarchical_agent is not None:  # agent/...:751-754
-                act, mean, ls, goal = self.hierarchical_agent.act(state, eps, clamp=self.safety_layer is None)
+                eps = None if deterministic else torch.randn((state.shape[0], self.action_dim), device=self.device, generator=self._gen)
+                act, mean, ls, goal = self.hierarchical_agent.act(state, eps, clamp=not raw)
             else:
-                act, mean, ls = self.sac.act(state, eps, clamp=self.safety_layer is None)
-            if self.safety_layer is not None:  # sees the raw sample, then the result is clamped (agent/...:785-789)
-                act = self.safety_layer.apply(state, act)
-            info = {"algorithm": "sac", "mean": mean.cpu().numpy(), "log_std": ls.cpu().numpy(), "value": None}
+                if algorithm not in self.algorithms:
+                    self.logger.warning(f"Algorithm {algorithm} not available, falling back to first available")
+                    algorithm = list(self.algorithms.keys())[0]
+                act, mean, ls = self._policy_action(algorithm, state, deterministic, clamp=not raw)
+            if raw:
+                act = self.safety_layer.apply(state, act.contiguous())
+            info = {"algorithm": algorithm, "mean": mean.cpu().numpy(), "log_std": ls.cpu().numpy(), "value": None}
             if goal is not None:
                 info["goal"] = goal.cpu().numpy()
             return act.cpu().numpy(), info
@@ -431,19 +511,36 @@ class MultiAlgorithmAgent:
     def update(self, batch: Dict, algorithm: Optional[str] = None):
         """-> dict of float losses like agent/...:868-912; never raises (returns {'error': msg})."""
         try:
+            if algorithm is None:
+                algorithm = self.select_algorithm()
             f = lambda k, shape: torch.as_tensor(batch[k]).to(device=self.device, dtype=torch.float32).reshape(shape).contiguous()
             B = int(torch.as_tensor(batch["states"]).reshape(-1, self.obs_dim).shape[0])
-            if B != self.batch_size:
-                raise ValueError(f"batch of {B} rows, agent built for tvc_native.batch_size={self.batch_size}")
             s, s2 = f("states", (B, self.obs_dim)), f("next_states", (B, self.obs_dim))
             a, r, d = f("actions", (B, self.action_dim)), f("rewards", (B,)), f("dones", (B,))
-            e1 = torch.randn((B, self.action_dim), device=self.device, generator=self._gen)
-            e2 = torch.randn((B, self.action_dim), device=self.device, generator=self._gen)
-            losses = self.sac.update(s, a, r, s2, d, e1, e2).cpu().tolist()
-            out = {"q1_loss": losses[0], "q2_loss": losses[1], "policy_loss": losses[2]}
-            if (self.config.get("physics_informed", {}) or {}).get("enabled", False) and losses[3] > 0:
-                out["physics_loss"] = losses[3]
-            return out
+            physics = (self.config.get("physics_informed", {}) or {}).get("enabled", False)
+            if algorithm == "sac" and "sac" in self.algorithms:
+                if B != self.batch_size:
+                    raise ValueError(f"batch of {B} rows, agent built for tvc_native.batch_size={self.batch_size}")
+                e1 = torch.randn((B, self.action_dim), device=self.device, generator=self._gen)
+                e2 = torch.randn((B, self.action_dim), device=self.device, generator=self._gen)
+                losses = self.sac.update(s, a, r, s2, d, e1, e2).cpu().tolist()
+                out = {"q1_loss": losses[0], "q2_loss": losses[1], "policy_loss": losses[2]}
+                if physics and losses[3] > 0:
+                    out["physics_loss"] = losses[3]
+                return out
+            if algorithm in ("ppo", "td3") and algorithm in self.algorithms:
+                from . import passthrough
+                tb = {"states": s, "actions": a, "rewards": r, "next_states": s2, "dones": d}
+                out = passthrough.update_ppo(self.algorithms["ppo"], tb) if algorithm == "ppo" \
+                    else passthrough.update_td3(self.algorithms["td3"], tb)
+                if physics:  # PhysicsInformedLoss (:236-285), reported only
+                    w = float((self.config.get("physics_informed", {}) or {}).get("physics_loss_weight", 0.1))
+                    pl = float(_physics_loss_eager(s, a, s2, w))
+                    if pl > 0:
+                        out["physics_loss"] = pl
+                return out
+            self.logger.warning(f"Algorithm {algorithm} not available for update")
+            return {}
         except Exception as e:
             self.logger.error(f"Error in agent update: {e}")
             return {"error": str(e)}
@@ -460,8 +557,15 @@ class MultiAlgorithmAgent:
     # deques, :1102), algorithm_weights, config.  The reference's own load_checkpoint reads a file written here (tested in the
     # build container against the reference class, tests/test_checkpoint_cpu.py), and a file the reference wrote loads here.
     def save_checkpoint(self, path: str):
+        entries = {}
+        for name, agent in self.algorithms.items():
+            if agent["type"] == "sac":
+                entries[name] = self.sac.export_checkpoint_entry()
+            else:
+                from . import passthrough
+                entries[name] = passthrough.checkpoint_entry(agent)
         ckpt_dict = {
-            "algorithms": {"sac": self.sac.export_checkpoint_entry()},
+            "algorithms": entries,
             "performance_history": dict(self.performance_history),
             "algorithm_weights": self.algorithm_weights,
             "config": self.config,
@@ -473,7 +577,14 @@ class MultiAlgorithmAgent:
         c = ckpt.load_file(path)  # weights-only loader, deque allow-listed
         self.performance_history = {k: deque(v, maxlen=100) for k, v in c["performance_history"].items()}
         self.algorithm_weights = c["algorithm_weights"]
-        entry = c["algorithms"]["sac"]
+        for name in ("ppo", "td3"):
+            e = c["algorithms"].get(name)
+            if name in self.algorithms and e is not None and "policy_state" in e:
+                from . import passthrough
+                passthrough.load_checkpoint_entry(self.algorithms[name], e)
+        entry = c["algorithms"].get("sac")
+        if entry is None or self.sac is None:
+            return
         have_opt = self.sac.import_checkpoint_entry(entry)
         if not have_opt and "native_adam" in entry:  # round-1 files
             self.sac.adam_m.copy_(entry["native_adam"]["m"])
