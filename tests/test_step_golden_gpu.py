@@ -225,6 +225,6 @@ def test_run_episode_shaped_loop_through_the_dropin_module_paths():
                 break
             obs = next_obs
         agent.update_performance(algorithm, episode_reward)
-    assert total_timesteps > 30 and {"policy_loss", "value_loss", "total_loss"} == set(losses) and algorithm == "ppo"
+    assert total_timesteps > 30 and {"policy_loss", "value_loss", "total_loss"} <= set(losses) and algorithm == "ppo"
     assert len(agent.performance_history[algorithm]) == 3
     env.close()
