@@ -61,6 +61,9 @@ def parse():
                                                                       "acting pass on the second stream)")
     ap.add_argument("--shipped-acting", action="store_true", help="train: act like the reference under its shipped config.yaml "
                                                                   "(hierarchical goal policy + safety layer + curiosity bonus)")
+    ap.add_argument("--exact-reward", action="store_true",
+                    help="reference-exact reward history: the diversity test of MultiObjectiveReward looks at the whole 1000-entry deque "
+                         "(env/...:221) instead of the last 10 rewards (4 KB of state per env)")
     ap.add_argument("--share-cus", choices=["auto", "on", "off"], default="auto",
                     help="train: one acting workgroup per CU so that the update runs beside the acting pass (auto: on with the two-stream schedule)")
     ap.add_argument("--no-overlap", action="store_true", help="train: run the update after the acting pass instead of beside it")

@@ -43,6 +43,13 @@ class VecTrainer:
         # alone but lets the update's kernels run BESIDE it, which wins at every update count (65 536 envs: 2.49 vs 2.58 ms per
         # step at 1 update per step, 2.74 vs 3.40 at 2, 4.18 vs 4.92 at 4; profiles/r02_f_bench_matrix.md).
         self.share_cus = bool(overlap) if share_cus is None else bool(share_cus)
+        # ... and only for as many rows as the update needs company: with ONE update per step the first half of the rows is
+        # acted on in the sharing form (2 rounds of 16 384 rows, 1.18 ms at 65 536 envs: the update runs beside them), the second
+        # half in the exclusive form (one round of 512 workgroups, 0.95 ms): 2.13 ms instead of 2.36 (all shared) or 1.89 + the
+        # update (all exclusive).  From two updates per step on, every row is shared.
+        self.share_rows = num_envs
+        if self.share_cus and updates_per_step <= 1 and num_envs >= 32768 and (num_envs // 2) % 64 == 0:
+            self.share_rows = num_envs // 2
         self._side = torch.cuda.Stream(self.device)
         self._fork = torch.cuda.Event()
         # intrinsic curiosity bonus of the reference's training env (scripts/train.py:318, env/...:496-502)
@@ -139,8 +146,15 @@ class VecTrainer:
             a, _, _, _ = self.hier.act(cur, self.eps_act, self.u_goal, clamp=self.safety is None)
             raw.copy_(a)
         else:
-            self.sac.act(cur, self.eps_act, out=(raw, self.mean, self.ls), clamp=self.safety is None, snapshot=self._snapshot,
-                         share_cus=self.share_cus and self._snapshot)
+            share = self.share_cus and self._snapshot
+            k = self.share_rows if share else self.n
+            if 0 < k < self.n:  # two launches over row blocks: [0, k) leaves room for the update, [k, n) takes the whole chip
+                for lo, hi, sh in ((0, k, True), (k, self.n, False)):
+                    self.sac.act(cur[lo:hi], self.eps_act[lo:hi], out=(raw[lo:hi], self.mean[lo:hi], self.ls[lo:hi]),
+                                 clamp=self.safety is None, snapshot=self._snapshot, share_cus=sh)
+            else:
+                self.sac.act(cur, self.eps_act, out=(raw, self.mean, self.ls), clamp=self.safety is None, snapshot=self._snapshot,
+                             share_cus=share)
         if self.safety is not None:  # sees the unclamped sample; clamps its result
             self.safety.apply(cur, raw, out=self.act)
         o, rew, term, trunc, info = self.env.step(self.act, out_obs=nxt)
@@ -273,6 +287,8 @@ def bench_train(args, world, rank, device, n_envs=None):
     if stage is not None:  # BASELINE configs[4]: full domain randomisation at a curriculum stage (config.yaml:236-286, 340-349)
         from .env import dr_from_yaml
         env_over = dr_from_yaml({}, stage)
+    if getattr(args, "exact_reward", False):
+        env_over["distinct_window"] = 1000
     shipped = bool(getattr(args, "shipped_acting", False))
     utd = max(1, int(getattr(args, "updates_per_step", 1)))
     tr = VecTrainer(n, device=device, family=family, batch_size=256, replay_capacity=1_000_000, seed=42,
@@ -293,8 +309,10 @@ def bench_train(args, world, rank, device, n_envs=None):
                                                       "utd": f"{utd} update(s) per vector step", "dtype": "f32 MFMA",
                                                       "dropout_in_update": tr.dropout_p,
                                                       "acting_kernel_shares_cus": tr.share_cus,
+                                                      "acting_rows_in_sharing_form": tr.share_rows if tr.share_cus else 0,
                                                       "acting": "hierarchical goal policy + safety layer + curiosity bonus (shipped config.yaml)"
                                                       if shipped else "SAC policy",
+                                                      "reward_history_window": int(tr.env.cfg.distinct_window),
                                                       "domain_randomisation": "off (shipped env)" if stage is None
                                                       else f"curriculum stage {stage} with the curriculum driver attached "
                                                            f"(device-side episode statistics): {env_over}"}}}
