@@ -181,8 +181,8 @@ class VecTrainer:
                 for k in range(self.updates_per_step):
                     self.learn(k)
         self.steps += 1
-        if self.curriculum is not None:
-            self._curriculum_tick()
+        if self.curriculum is not None and not torch.cuda.is_current_stream_capturing():
+            self._curriculum_tick()  # host-side bookkeeping (event query, pinned read-back): not part of a captured graph
 
     def _step_overlapped(self):
         """Same work as collect() + updates_per_step x learn(), on two HIP streams.  The acting pass (large GEMMs over
