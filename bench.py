@@ -581,7 +581,9 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
                                "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc pass, not measured in this run)" if traffic else None,
                                "launch_us": us, "launch_us_source": "live: hipGraph of 5 isolated launches, HIP events on their stream",
                                "in_loop_us": loop,
-                               "in_loop_source": f"{LOOP_STATS_FILE} (committed rocprofv3 --kernel-trace --stats of the train loop)" if loop else None,
+                               "in_loop_source": (f"{LOOP_STATS_FILE} (committed rocprofv3 --kernel-trace --stats of the train loop; per-step "
+                                                  "total of the loop's TWO launches of n/2 rows: one beside the learner at 1 workgroup "
+                                                  "per CU, one alone)") if loop else None,
                                "in_loop_frac": (flops / (loop * 1e-6) / 1e12 / MFMA_F32_PEAK_TF) if loop else None,
                                "flops_per_launch": flops, "flops_per_row": 2.0 * macs, "clock": clock, "dtype": "f32 in / f32 acc MFMA"}
         else:
@@ -647,20 +649,25 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
                                              "safety": {"safety_layer": {"enabled": True}}}, device=device)
             def loop(algorithm, budget):
                 obs, _ = env1.reset()
-                n1 = 0
+                n1 = skipped = 0
                 t0 = time.perf_counter()
                 while n1 < 200 and time.perf_counter() - t0 < budget:
                     a, _ = ag.get_action(torch.from_numpy(obs).unsqueeze(0), algorithm=algorithm)
                     nobs, r, term, trunc, _ = env1.step(a.flatten())
-                    ag.update({"states": torch.from_numpy(obs).unsqueeze(0), "actions": torch.from_numpy(a),
-                               "rewards": torch.tensor([r]), "next_states": torch.from_numpy(nobs).unsqueeze(0),
-                               "dones": torch.BoolTensor([term or trunc])}, algorithm=algorithm)
+                    out = ag.update({"states": torch.from_numpy(obs).unsqueeze(0), "actions": torch.from_numpy(a),
+                                     "rewards": torch.tensor([r]), "next_states": torch.from_numpy(nobs).unsqueeze(0),
+                                     "dones": torch.BoolTensor([term or trunc])}, algorithm=algorithm)
+                    skipped += 0 if out else 1  # like the reference, update() logs and swallows an exception (agent/...:908-912)
                     obs = env1.reset()[0] if (term or trunc) else nobs
                     n1 += 1
-                return n1 / (time.perf_counter() - t0), n1
-            sps_ref, n_ref = loop(None, 6.0)   # what scripts/train.py does: select_algorithm() -> 'ppo' (eager pass-through update)
-            sps_sac, n_sac = loop("sac", 6.0)  # the same loop pinned to the accelerated learner
-            rep["reference_plumbing_n1"] = {"steps_per_s": sps_sac, "steps": n_sac, "steps_per_s_default_selection_ppo_passthrough": sps_ref,
+                return n1 / (time.perf_counter() - t0), n1, skipped
+            import logging
+            ag.logger.setLevel(logging.CRITICAL)  # the simplified B = 1 PPO update (agent/...:914-948) can diverge; counted below instead
+            sps_ref, n_ref, skip_ref = loop(None, 6.0)   # scripts/train.py: select_algorithm() -> 'ppo' (eager pass-through update)
+            sps_sac, n_sac, skip_sac = loop("sac", 6.0)  # the same loop pinned to the accelerated learner
+            rep["reference_plumbing_n1"] = {"steps_per_s": sps_sac, "steps": n_sac, "updates_skipped": skip_sac,
+                                            "steps_per_s_default_selection_ppo_passthrough": sps_ref,
+                                            "updates_skipped_default_selection": skip_ref,
                                             "config": "config.yaml defaults: hierarchical goal policy + safety layer + curiosity + physics-informed loss on",
                                             "note": "1 env + 1 online update per step through the reference's Python surface (host round "
                                                     "trips every call); steps_per_s = algorithm 'sac' (HIP learner), the other figure = the "
