@@ -492,6 +492,54 @@ def test_gradients_match_autograd_of_the_restatement(dropout_p):
     sac.close()
 
 
+def test_acting_in_train_mode_applies_the_reference_dropout_sites():
+    """get_action of the reference runs the policy in train mode (no .eval() anywhere, agent/...:765): attention-weight dropout
+    (whole heads of V at sequence length 1), dropout1 / FFN dropout / dropout2 of every encoder layer and the two head Dropouts.
+    tvc_sac_act flags bit 3 = NativeSAC.act(train_mode=True) against the restatement with the kernels' own hash masks (site base
+    300, counter = number of train-mode acting calls so far), element for element; then the statistics of the masks."""
+    from tvc_ai_amd.agent import NativeSAC, sac_cfg
+    from tests import parity_log
+    torch.set_num_threads(8)
+    rec = _recipe()
+    meta = json.load(open(os.path.join(HERE, "golden", "sac_ref_meta.json")))
+    rng = np.random.default_rng(meta["seed"])
+    nets = ref_nets(rec, meta, rng)
+    n, p = 300, 0.1
+    sac = NativeSAC(sac_cfg(0, batch_size=64, max_act_rows=512, dropout_p=p), init=False)
+    load_into_native(sac, nets)
+    P = {k: v.clone() for k, v in nets["policy"].items()}
+    obs = torch.from_numpy(rng.standard_normal((n, 10)).astype(np.float32))
+    eps = torch.from_numpy(rng.standard_normal((n, 2)).astype(np.float32))
+    og, eg = cuda(obs, eps)
+    masks = st.DropMasks(p)
+    worst = 0.0
+    outs = []
+    for call in range(3):
+        act, mean, ls = sac.act(og, eg, train_mode=True)
+        with torch.no_grad():
+            m_ref, ls_ref = st.actor_forward(P, obs, False, drop=masks.hook(call, 300))
+        a_ref = torch.clamp(m_ref + torch.exp(ls_ref) * eps, -1, 1)
+        for got, want in ((mean, m_ref), (ls, ls_ref), (act, a_ref)):
+            err = (got.cpu() - want).abs().max().item()
+            worst = max(worst, err)
+            assert err <= 2e-4 * max(1.0, want.abs().max().item()), (call, err)
+        outs.append(mean.cpu().clone())
+    assert (outs[0] - outs[1]).abs().max().item() > 1e-3  # fresh masks every call
+    # the eval-mode pass is a different function of the same weights, and the train-mode outputs scatter around it
+    _, mean_eval, _ = sac.act(og, eg)
+    with torch.no_grad():
+        m_eval_ref, _ = st.actor_forward(P, obs, False)
+    assert (mean_eval.cpu() - m_eval_ref).abs().max().item() <= 2e-4 * max(1.0, m_eval_ref.abs().max().item())
+    assert (outs[0] - mean_eval.cpu()).abs().max().item() > 1e-3
+    # a handle without dropout refuses the flag instead of silently acting in eval mode
+    sac0 = NativeSAC(sac_cfg(0, batch_size=64, max_act_rows=512, dropout_p=0.0), init=False)
+    with pytest.raises(Exception):
+        sac0.act(og, eg, train_mode=True)
+    sac0.close()
+    sac.close()
+    parity_log.record("test_acting_in_train_mode_applies_the_reference_dropout_sites", rows=n, calls=3, worst_abs_err=worst)
+
+
 @pytest.mark.parametrize("M,N,K,act", [(8192, 256, 512, 0), (6145, 256, 256, 0), (7000, 512, 256, 1), (6400, 512, 512, 1)])
 def test_fused_linear_layernorm_kernel_vs_torch_fp32(M, N, K, act):
     """the acting-pass kernel (Linear + act + residual + LayerNorm in one launch, 32 complete rows per workgroup) on its own"""

@@ -223,17 +223,19 @@ class NativeSAC:
         nat.check(self.L.tvc_sac_snapshot_policy(self._h, self._stream()))
 
     def act(self, obs: torch.Tensor, eps: Optional[torch.Tensor] = None, out=None, clamp: bool = True, snapshot: bool = False,
-            share_cus: bool = False):
+            share_cus: bool = False, train_mode: bool = False):
         """-> (action[n,A] clamped to [-1,1] unless clamp=False, mean, log_std); eps None = deterministic.
         snapshot=True acts with the parameters of the last snapshot_policy() instead of the live ones; share_cus=True leaves
-        half of every CU to other streams (tvc_sac_act flags bit 2)."""
+        half of every CU to other streams (tvc_sac_act flags bit 2); train_mode=True keeps Dropout active while acting, as the
+        reference does (it never calls .eval(), agent/...:765): flags bit 3, per-layer kernels, fresh masks every call."""
         n, A = obs.shape[0], self.cfg.act_dim
         assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.cfg.obs_dim
         if out is None:
             out = tuple(torch.empty((n, A), dtype=torch.float32, device=self.device) for _ in range(3))
         act, mean, ls = out
         nat.check(self.L.tvc_sac_act(self._h, obs.data_ptr(), n, nat.ptr(eps), act.data_ptr(), mean.data_ptr(), ls.data_ptr(),
-                                     (0 if clamp else 1) | (2 if snapshot else 0) | (4 if share_cus else 0), self._stream()))
+                                     (0 if clamp else 1) | (2 if snapshot else 0) | (4 if share_cus else 0) | (8 if train_mode else 0),
+                                     self._stream()))
         return act, mean, ls
 
     def update(self, s, a, r, s2, d, eps_next, eps_new, all_reduce=None, grad_scale: float = 1.0):
@@ -400,10 +402,14 @@ class MultiAlgorithmAgent:
                           # for the policy, a hard-coded 0.1 in the critics, agent/...:457,596-604); one value drives both here
                           dropout_p=float(native.get("dropout", tr.get("dropout", 0.1))) if family == 0 else 0.0)
             self.sac = NativeSAC(cfg, device=self.device, seed=seed)
+            # ... and neither does its get_action: the policy acts with Dropout active (agent/...:765).  Mirrored by default
+            # (tvc_native.acting_dropout: false = act with the deterministic net, what VecTrainer does for throughput)
+            self._act_train_mode = bool(native.get("acting_dropout", True)) and cfg.dropout_p > 0.0
             self.algorithms["sac"] = {"type": "sac", "native": self.sac}
             self.algorithm_weights["sac"] = 1.0
         else:
             self.sac = None
+            self._act_train_mode = False
         if enabled("td3") and passthrough_on:
             from . import passthrough
             torch.manual_seed(seed + 103)
@@ -460,7 +466,7 @@ class MultiAlgorithmAgent:
         agent = self.algorithms[name]
         if agent["type"] == "sac":
             eps = None if deterministic else torch.randn((state.shape[0], self.action_dim), device=self.device, generator=self._gen)
-            return self.sac.act(state, eps, clamp=clamp)
+            return self.sac.act(state, eps, clamp=clamp, train_mode=self._act_train_mode)
         from . import passthrough
         with torch.no_grad():
             mean, log_std, _ = passthrough.policy_outputs(agent, state)

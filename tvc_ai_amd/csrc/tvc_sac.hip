@@ -352,7 +352,7 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
             a.Z = (save && o.act != ACT_NONE) ? c.Z[out] : nullptr;
             // MLP family acting: input layer -> hidden Linear (+act) -> output head as ONE launch; the input layer is
             // evaluated inside the hidden layer's k-loop
-            if (!save && G == 1 && M >= fuse_ln_min_rows() && o.src == 0 && !in2 && !o.rowtab && o.mul < 0 && o.out_dim <= 256 &&
+            if (!save && !dc && G == 1 && M >= fuse_ln_min_rows() && o.src == 0 && !in2 && !o.rowtab && o.mul < 0 && o.out_dim <= 256 &&
                 (o.out_dim % GBK) == 0 && i + 2 < (int)nd.ops.size() && nd.last_use[out] == i + 1) {
                 const Op& h = nd.ops[i + 1];
                 const Op& ho = nd.ops[i + 2];
@@ -369,7 +369,7 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
                     continue;
                 }
             }
-            if (!save && G == 1 && o.out_dim == 256 && o.mul < 0 && !(o.rowtab && pe) && i + 1 < (int)nd.ops.size() &&
+            if (!save && !dc && G == 1 && o.out_dim == 256 && o.mul < 0 && !(o.rowtab && pe) && i + 1 < (int)nd.ops.size() &&
                 nd.ops[i + 1].type == OP_LN && nd.ops[i + 1].src == out && nd.last_use[out] == i + 1) {
                 const Op& ln = nd.ops[i + 1];  // thin Linear + LayerNorm in one launch (the folded embedding block)
                 a.Y = c.Y[out + 1];
@@ -382,7 +382,7 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
         }
         // acting pass (nothing saved, many rows): Linear (+act, +residual) and the LayerNorm(s) behind it in ONE launch,
         // 32 complete rows per workgroup
-        if (o.type == OP_LINEAR && !save && G == 1 && M >= fuse_ln_min_rows() && !o.rowtab && (o.in_dim % GBK) == 0 &&
+        if (o.type == OP_LINEAR && !save && !dc && G == 1 && M >= fuse_ln_min_rows() && !o.rowtab && (o.in_dim % GBK) == 0 &&
             (o.out_dim == 256 || o.out_dim == 512) && i + 1 < (int)nd.ops.size() && nd.ops[i + 1].type == OP_LN &&
             nd.ops[i + 1].src == out && nd.last_use[out] == i + 1 && g_force_variant == 0) {
             const Op& ln = nd.ops[i + 1];
@@ -412,7 +412,7 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
         }
         // acting pass of the MLP family: hidden Linear (+ReLU) and the output head behind it in one launch (the hidden
         // activation is never written)
-        if (o.type == OP_LINEAR && !save && G == 1 && M >= fuse_ln_min_rows() && !o.rowtab && o.res < 0 && (o.in_dim % GBK) == 0 &&
+        if (o.type == OP_LINEAR && !save && !dc && G == 1 && M >= fuse_ln_min_rows() && !o.rowtab && o.res < 0 && (o.in_dim % GBK) == 0 &&
             (o.out_dim == 256 || o.out_dim == 512) && i + 1 < (int)nd.ops.size() && nd.ops[i + 1].type == OP_HEAD &&
             nd.ops[i + 1].src == out && nd.last_use[out] == i + 1 && nd.ops[i + 1].out_dim <= 4 && g_force_variant == 0) {
             const Op& ho = nd.ops[i + 1];
@@ -592,6 +592,7 @@ __global__ void concat_kernel(const float* __restrict__ s, const float* __restri
 }
 
 // head output [M,2A] -> mean, clamped log_std, action = mean + exp(log_std) * eps  (agent/...:224-225, 780-782, 964-966)
+__global__ void act_ctr_tick_kernel(int* ctr) { *ctr += 1; }
 __global__ void sample_action_kernel(const float* __restrict__ head, const float* __restrict__ eps, float* __restrict__ act,
                                      float* __restrict__ mean_out, float* __restrict__ ls_out, int M, int A, int clamp_act) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -761,6 +762,9 @@ struct tvc_sac {
     float *params, *grads, *adam_m, *adam_v;  // caller-owned
     void* slab = nullptr;                      // library-owned workspace
     Ctx actx, cctx, ictx;                      // actor (train), critics (train, G=2), actor (inference, slot-aliased)
+    Ctx dctx;                                  // actor as trained (unfolded, dropout sites), slot-aliased: acting in train mode
+    bool dctx_ok = false;
+    int* act_ctr = nullptr;                    // dropout counter of the train-mode acting calls (advanced by each call)
     float *xs2 = nullptr;   // [2B, obs]: states and next states stacked for the single actor forward of an update
     bool actor_fwd_valid = false;
     bool grads_clean[2] = {false, false};  // critics, actor: zeroed by the Adam kernel since they were last written
@@ -977,6 +981,8 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     h->ov_floats = (long)std::max(1, h->fold.layers) * ((long)h->fold.d * h->fold.d + h->fold.d + 4) +
                    (long)h->fold.d * (h->fold.obs + 1) + 8;
     bytes += 2 * h->ov_floats * 4 + h->n_actor * 4 + 2048;
+    const bool want_dctx = cfg->family == 0 && cfg->dropout_p > 0.0f && !cfg->use_se;
+    if (want_dctx) bytes += 8L * NA * maxd * 4 + 4096;
     std::vector<PackTile> ptiles;
     std::vector<PackVec> pvecs;
     h->rows_ok = rows_supported(*cfg, h->fold);
@@ -1001,6 +1007,10 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
         (void)hipFree(h->slab);
         delete h;
         return tvc::set_error(TVC_EINVAL, "inference slot allocation failed");
+    }
+    if (want_dctx) {
+        h->dctx_ok = ctx_alloc_infer(h->dctx, h->actor, NA, p) == 0;
+        h->act_ctr = (int*)carve(p, 16);
     }
     h->pe = (float*)carve(p, (long)cfg->pe_rows * cfg->d_model * 4);
     h->xcat = (float*)carve(p, (long)B * (cfg->obs_dim + A) * 4);
@@ -1079,6 +1089,22 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
     // activation group strides depend on the row count actually used
     for (size_t b = 1; b < h->ictx.gY.size(); ++b) h->ictx.gY[b] = (long)n * h->actor_inf.buf_dim[b];
     const bool snap = (flags & 2) != 0;  // read the snapshot taken by tvc_sac_snapshot_policy instead of the live parameters
+    if (flags & 8) {
+        // acting in TRAIN mode, like the reference, which never calls .eval() (agent/...:765): the net as trained (attention not
+        // folded -- the attention-weight dropout zeroes whole heads of V) with fresh masks at every dropout site per call
+        if (!h->dctx_ok) return tvc::set_error(TVC_EINVAL, "train-mode acting needs family 0 with dropout_p > 0 (and no use_se)");
+        for (size_t b = 1; b < h->dctx.gY.size(); ++b) h->dctx.gY[b] = (long)n * h->actor.buf_dim[b];
+        DropCtl dc;
+        dc.ctr = h->act_ctr; dc.thresh = (unsigned)lroundf(h->cfg.dropout_p * 65536.0f);
+        dc.scale = 65536.0f / (float)(65536u - dc.thresh); dc.site_base = 300;
+        net_forward(h->actor, snap ? h->snap_p : h->P_actor(), 0, obs, 0, n, 1, h->dctx, false, h->pe, h->cfg.pe_rows, st, nullptr,
+                    nullptr, &dc);
+        hipLaunchKernelGGL(sample_action_kernel, dim3((n * A + 255) / 256), dim3(256), 0, st, h->dctx.Y.back(), eps, act, mean, logstd,
+                           n, A, (flags & 1) ? 0 : 1);
+        hipLaunchKernelGGL(act_ctr_tick_kernel, dim3(1), dim3(1), 0, st, h->act_ctr);
+        TVC_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (h->rows_ok && n >= rows_min_rows() && g_force_variant == 0) {  // the whole pass as one launch (tvc_actor_rows.h)
         const float* pk = snap ? h->snap_pack : h->pack;
         ActRowsArgs a{};
