@@ -238,7 +238,7 @@ int tvc_sac_set_adam_steps(tvc_sac* sac, const int32_t in[2]);
  * bit 2: share the CUs -- the one-launch acting kernel (n >= 12 288 rows, reference shapes) then occupies half of each CU's
  * registers instead of all of them, so that kernels on other streams (a SAC update) run beside it instead of after it;
  * bit 3: act in TRAIN mode like the reference's get_action (no .eval() anywhere, agent/...:765): Dropout active at every site of
- * the policy with fresh masks per call (needs family 0, dropout_p > 0, no use_se; per-layer kernels, attention not folded).
+ * the policy with fresh masks per call (needs family 0 and dropout_p > 0; per-layer kernels, attention not folded).
  * obs_dev float[n,obs]; act_dev float[n,A]; mean_dev / logstd_dev float[n,A] or NULL. */
 int tvc_sac_act(tvc_sac* sac, const float* obs_dev, int32_t n, const float* eps_dev, float* act_dev, float* mean_dev,
                 float* logstd_dev, int32_t flags, void* stream);

@@ -88,7 +88,7 @@ def actor_forward(P, obs, batch_pe=False, n_layers=4, drop=None, nhead=8):
         f = drop(4 + 6 * l, F.gelu(x @ P[pre + "linear1.weight"].T + P[pre + "linear1.bias"]))
         f = drop(5 + 6 * l, f @ P[pre + "linear2.weight"].T + P[pre + "linear2.bias"])
         x = _ln(x + f, P, pre + "norm2")
-    base = 1 + 6 * n_layers
+    base = 1 + 6 * n_layers + (2 if "se_block.fc1.weight" in P else 0)  # the SE block is two ops of the native net
     x = _ln(x, P, "feature_norm")
     if "se_block.fc1.weight" in P:  # SqueezeExcitation (agent/...:104-118): pooling a [B, C, 1] tensor over its last axis is the identity
         y = F.relu(x @ P["se_block.fc1.weight"].T + P["se_block.fc1.bias"])

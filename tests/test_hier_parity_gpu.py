@@ -9,9 +9,9 @@ from tests.test_hier_oracle_golden import hier_setup
 pytestmark = pytest.mark.gpu
 
 
-def _policy(H, P, pe_rows=1, max_rows=4096):
+def _policy(H, P, pe_rows=1, max_rows=4096, train_mode=False):
     from tvc_ai_amd.hierarchical import HierarchicalPolicy
-    hp = HierarchicalPolicy(10, 2, device="cuda:0", max_rows=max_rows, seed=0, pe_rows=pe_rows)
+    hp = HierarchicalPolicy(10, 2, device="cuda:0", max_rows=max_rows, seed=0, pe_rows=pe_rows, train_mode=train_mode)
     hp.high.load_state_dict(H)
     hp.low.load_reference_state("policy", P)
     return hp
@@ -59,6 +59,29 @@ def test_goal_draw_and_fused_act_path():
     np.testing.assert_allclose(ls.cpu().numpy(), ol.numpy(), atol=2e-4)
     want_act = torch.clamp(om + torch.exp(ol) * eps, -1, 1)
     np.testing.assert_allclose(act.cpu().numpy(), want_act.numpy(), atol=1e-3)
+    hp.close()
+
+
+def test_low_level_policy_in_train_mode_like_the_reference():
+    """the reference's hierarchical nets are never put in eval mode either: the goal-conditioned TransformerPolicyNetwork acts with
+    Dropout(0.1) active.  Same masks on both sides (DropMasks, site base 300, call counter), SE block included."""
+    g, H, P, s, goal = hier_setup()
+    d = torch.device("cuda:0")
+    hp = _policy(H, P, pe_rows=1, train_mode=True)
+    sd, gd = torch.from_numpy(s).to(d), torch.from_numpy(goal).to(d)
+    onehot = torch.nn.functional.one_hot(torch.from_numpy(goal).long(), 4).float()
+    sg = torch.cat([torch.from_numpy(s), onehot], -1)
+    Pt = {k: torch.as_tensor(v) for k, v in P.items()}
+    masks = st.DropMasks(0.1)
+    outs = []
+    for call in range(2):
+        mean, ls, _ = hp.get_action(sd, gd)
+        with torch.no_grad():
+            m_ref, ls_ref = st.actor_forward(Pt, sg, False, drop=masks.hook(call, 300))
+        np.testing.assert_allclose(mean.cpu().numpy(), m_ref.numpy(), atol=2e-4)
+        np.testing.assert_allclose(ls.cpu().numpy(), ls_ref.numpy(), atol=2e-4)
+        outs.append(mean.cpu())
+    assert (outs[0] - outs[1]).abs().max().item() > 1e-3
     hp.close()
 
 

@@ -433,7 +433,8 @@ class MultiAlgorithmAgent:
         if (self.config.get("hierarchical_rl", {}) or {}).get("enabled", False):
             from .hierarchical import HierarchicalPolicy
             self.hierarchical_agent = HierarchicalPolicy(obs_dim, action_dim, device=self.device,
-                                                         max_rows=int(native.get("max_act_rows", 4096)), seed=seed)
+                                                         max_rows=int(native.get("max_act_rows", 4096)), seed=seed,
+                                                         train_mode=bool(native.get("acting_dropout", True)))
 
     def to(self, device):
         if torch.device(device).type != self.device.type:

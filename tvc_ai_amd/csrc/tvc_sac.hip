@@ -981,7 +981,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     h->ov_floats = (long)std::max(1, h->fold.layers) * ((long)h->fold.d * h->fold.d + h->fold.d + 4) +
                    (long)h->fold.d * (h->fold.obs + 1) + 8;
     bytes += 2 * h->ov_floats * 4 + h->n_actor * 4 + 2048;
-    const bool want_dctx = cfg->family == 0 && cfg->dropout_p > 0.0f && !cfg->use_se;
+    const bool want_dctx = cfg->family == 0 && cfg->dropout_p > 0.0f;
     if (want_dctx) bytes += 8L * NA * maxd * 4 + 4096;
     std::vector<PackTile> ptiles;
     std::vector<PackVec> pvecs;
@@ -1092,7 +1092,7 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
     if (flags & 8) {
         // acting in TRAIN mode, like the reference, which never calls .eval() (agent/...:765): the net as trained (attention not
         // folded -- the attention-weight dropout zeroes whole heads of V) with fresh masks at every dropout site per call
-        if (!h->dctx_ok) return tvc::set_error(TVC_EINVAL, "train-mode acting needs family 0 with dropout_p > 0 (and no use_se)");
+        if (!h->dctx_ok) return tvc::set_error(TVC_EINVAL, "train-mode acting needs family 0 with dropout_p > 0");
         for (size_t b = 1; b < h->dctx.gY.size(); ++b) h->dctx.gY[b] = (long)n * h->actor.buf_dim[b];
         DropCtl dc;
         dc.ctr = h->act_ctr; dc.thresh = (unsigned)lroundf(h->cfg.dropout_p * 65536.0f);

@@ -22,7 +22,9 @@ GOALS = ["hover", "land", "recover", "maintain_altitude"]  # agent/...:362
 
 class HierarchicalPolicy:
     def __init__(self, obs_dim: int = 10, action_dim: int = 2, device="cuda:0", max_rows: int = 4096, seed: int = 0,
-                 pe_rows: int = 1):
+                 pe_rows: int = 1, train_mode: bool = False, dropout_p: float = 0.1):
+        """train_mode=True: the low-level policy acts with its Dropout(NetworkConfig().dropout = 0.1) active, as in the reference,
+        whose nets are never put in eval mode (agent/...:377-381, 765); False = the deterministic net the goldens pin."""
         self.L = nat.load()
         self.device = torch.device(device)
         self.obs_dim, self.action_dim, self.goal_dim = obs_dim, action_dim, len(GOALS)
@@ -32,7 +34,9 @@ class HierarchicalPolicy:
                              layernorm=True)
         # low-level policy (:377-381): TransformerPolicyNetwork(obs + goals, A, NetworkConfig()); acting only
         self.low = NativeSAC(sac_cfg(0, obs_dim=obs_dim + self.goal_dim, act_dim=action_dim, use_se=1, batch_size=1,
-                                     max_act_rows=max_rows, pe_rows=pe_rows), device=self.device, seed=seed + 1)
+                                     max_act_rows=max_rows, pe_rows=pe_rows,
+                                     dropout_p=dropout_p if train_mode else 0.0), device=self.device, seed=seed + 1)
+        self.train_mode = bool(train_mode) and dropout_p > 0.0
         g = torch.Generator().manual_seed(seed + 2)
         self.goal_embedding = torch.randn(self.goal_dim, 32, generator=g)  # nn.Embedding(4, 32) (:384), unused by the reference
         self._gen = torch.Generator(device=self.device).manual_seed(seed + 3)
@@ -70,11 +74,11 @@ class HierarchicalPolicy:
         """-> (mean, log_std, None) for the given goals, like HierarchicalAgent.get_action (the value head is dead compute)"""
         onehot = torch.nn.functional.one_hot(goal_idx.long(), self.goal_dim).to(torch.float32)
         sg = torch.cat([state, onehot], dim=-1).contiguous()
-        _, mean, ls = self.low.act(sg, None, clamp=False)
+        _, mean, ls = self.low.act(sg, None, clamp=False, train_mode=self.train_mode)
         return mean, ls, None
 
     def act(self, state: torch.Tensor, eps: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None, clamp: bool = True):
         """select_goal + get_action + Normal sample in four launches' worth of host calls: -> (action, mean, log_std, goal_idx)"""
         sg = self._prepare(state.contiguous(), u)
-        act, mean, ls = self.low.act(sg, eps, clamp=clamp)
+        act, mean, ls = self.low.act(sg, eps, clamp=clamp, train_mode=self.train_mode)
         return act, mean, ls, self._goal_idx[:state.shape[0]]
