@@ -247,6 +247,10 @@ int tvc_sac_act(tvc_sac* sac, const float* obs_dev, int32_t n, const float* eps_
  * holds inside it (Delta s_memtime / Delta s_memrealtime x 100 MHz, median over workgroups of the last of `launches` back-to-back
  * launches) -- out[0] = MHz, out[1] = median workgroup lifetime in microseconds, out[2] = workgroups.  Synchronises. */
 int tvc_debug_rows_clock(tvc_sac* sac, const float* obs_dev, int32_t n, int32_t launches, double* out, void* stream);
+/* ... and the raw stamps of the last of those launches: 6 x uint64 per workgroup {s_memtime, s_memrealtime (100 MHz) at start, the
+ * same at the end, XCC_ID, HW_ID} into a HOST buffer of ceil(n / 64) * 6 entries; flags bit 2 as in tvc_sac_act.  Synchronises. */
+int tvc_debug_rows_stamps(tvc_sac* sac, const float* obs_dev, int32_t n, int32_t launches, int32_t flags, uint64_t* out_host,
+                          void* stream);
 
 /* One _update_sac (agent/...:950-1016) on a batch of batch_size rows, in four phases so that the caller can
  * all-reduce gradients between them (data parallel, K10):

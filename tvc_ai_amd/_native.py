@@ -88,6 +88,7 @@ SIGNATURES.update({
     "tvc_sac_snapshot_policy": (C.c_int, [_VP, _VP]),
     "tvc_sac_act": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, C.c_int32, _VP]),
     "tvc_debug_rows_clock": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.POINTER(C.c_double), _VP]),
+    "tvc_debug_rows_stamps": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), _VP]),
     "tvc_mlp_param_count": (C.c_int64, [C.POINTER(C.c_int32), C.c_int32]),
     "tvc_mlp_tensor_offset": (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "tvc_mlp_layout": (C.c_int64, [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),

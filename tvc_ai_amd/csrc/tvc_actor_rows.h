@@ -40,21 +40,33 @@ struct ActRowsArgs {
     float* act; float* mean; float* logstd;      // [M, A]; mean / logstd may be nullptr
     const float4* tiles; const float* vec;       // packed weights
     int M, obs_dim, A, clamp_act, n_layers, n_tiles;
-    unsigned long long* stamps;  // diagnostics (tvc_debug_rows_clock): per workgroup {s_memtime, s_memrealtime} at start and end
+    unsigned long long* stamps;  // diagnostics (tvc_debug_rows_clock): per workgroup {s_memtime, s_memrealtime} at start and end, XCC_ID, HW_ID
 };
 
+#ifdef AR_TRACE
+#define AR_STAMPS 96
+#define AR_T() do { if (a.stamps && tid == 0 && tr < AR_STAMPS) a.stamps[(long)AR_STAMPS * blockIdx.x + tr++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AR_STAMPS 6
+#define AR_T() do {} while (0)
+#endif
 struct ArPipe {
     const float4* tiles; float4* Bs;
     int ti, n_tiles, wave, lane;
 };
+#ifndef AR_NBUF
+#define AR_NBUF 2   // LDS tile buffers: 2 = copy one tile ahead; 4 = copy two tiles ahead (experiment, profiles/r02_c_actor_rows.md)
+#endif
 __device__ __forceinline__ void ar_issue_tile(const ArPipe& p, int ti) {
     // 16 KB = 4 waves x 4 wave-instructions x 1 KB, lane-linear image: LDS byte i of the tile = global byte i
     const float4* src = p.tiles + (long)ti * AR_TILE_F4 + p.wave * 256 + p.lane;
-    float4* dst = p.Bs + (ti & 1) * AR_TILE_F4 + p.wave * 256;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 64),
-                                         (__attribute__((address_space(3))) void*)(dst + j * 64), 16, 0, 0);
+    float4* dst = p.Bs + (ti & (AR_NBUF - 1)) * AR_TILE_F4 + p.wave * 256;
+    // one address pair; the four 1 KB pieces go through the instruction's immediate offset, which advances both the global and
+    // the LDS address (checked by tools/micro/mfma_lds.hip) -- separate pointers cost an M0 write + readfirstlane per piece (-3 %)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 2048, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 3072, 0);
 }
 // Make tile p.ti readable, start the copy of tile p.ti + 1 into the buffer that tile p.ti - 1 just vacated, return the readable
 // tile.  __syncthreads() here is: wait for my quarter of tile ti (vmcnt(0): the LDS-DMA is a pending LDS write) and for my
@@ -62,9 +74,27 @@ __device__ __forceinline__ void ar_issue_tile(const ArPipe& p, int ti) {
 // other buffer.  (An inline-asm wait instead hides the counters from hipcc's waitcnt pass, which then answers every later
 // fragment use with a full lgkmcnt(0); three buffers / two tiles ahead measured the same, profiles/r02_c_actor_rows.md.)
 __device__ __forceinline__ const float4* ar_next(ArPipe& p) {
+#if defined(AR_ABL) && AR_ABL == 1   // timing-only ablation: no workgroup barrier (waits kept)
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_sched_barrier(0);
+    const float4* cur = p.Bs + (p.ti & 1) * AR_TILE_F4;
+    if (p.ti + 1 < p.n_tiles) ar_issue_tile(p, p.ti + 1);
+#elif defined(AR_ABL) && AR_ABL == 3 // timing-only ablation: no weight copies at all (barrier kept)
+    __syncthreads();
+    const float4* cur = p.Bs + (p.ti & 1) * AR_TILE_F4;
+#elif AR_NBUF == 2
     __syncthreads();
     const float4* cur = p.Bs + (p.ti & 1) * AR_TILE_F4;
     if (p.ti + 1 < p.n_tiles) ar_issue_tile(p, p.ti + 1);
+#else
+    // two tiles ahead: tile ti + 2 goes to the buffer of tile ti - 2, whose fragment reads every wave consumed long ago (no LDS
+    // counter wait needed); of the copies in flight only tile ti's must have landed, tile ti + 1's four may stay outstanding
+    if (p.ti + 1 < p.n_tiles) __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4), expcnt / lgkmcnt untouched
+    else __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    const float4* cur = p.Bs + (p.ti & (AR_NBUF - 1)) * AR_TILE_F4;
+    if (p.ti + 2 < p.n_tiles) ar_issue_tile(p, p.ti + 2);
+#endif
     p.ti += 1;
     return cur;
 }
@@ -80,8 +110,17 @@ __device__ __forceinline__ void ar_mfma16(const float4 (&w)[4], const f32x4 xk, 
 }
 // the four weight fragments of group g: lane (l15, q) reads image[q][16 (4 g + j) + l15], conflict-free ds_read_b128
 __device__ __forceinline__ void ar_frag4(float4 (&w)[4], const float4* __restrict__ base, int g) {
+#if defined(AR_ABL) && AR_ABL == 2   // timing-only ablation: no LDS fragment reads (values made up in registers)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float t = __builtin_bit_cast(float, (int)(long)base + g + j);
+        asm volatile("" : "+v"(t));
+        w[j] = make_float4(t, t, t, t);
+    }
+#else
 #pragma unroll
     for (int j = 0; j < 4; ++j) w[j] = base[(4 * g + j) * 16];
+#endif
 }
 // order inside one fragment group: 8 MFMAs, the 4 fragment reads of the NEXT group, 8 MFMAs -- the reads are then ~256 cycles old
 // when the next group's first MFMA waits for them (hipcc answers that use with a full lgkmcnt(0), so reads issued right before
@@ -150,16 +189,25 @@ __device__ __forceinline__ void ar_layernorm(f32x4* __restrict__ u, const float*
 }
 
 __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
-    __shared__ __attribute__((aligned(16))) float4 Bs[2 * AR_TILE_F4];  // the ONLY LDS object: two 16 KB weight-tile buffers
+    __shared__ __attribute__((aligned(16))) float4 Bs[AR_NBUF * AR_TILE_F4];  // the ONLY LDS object: the 16 KB weight-tile buffers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const int row = blockIdx.x * 64 + wave * 16 + l15;
     const int rowc = min(row, a.M - 1);
     if (a.stamps && tid == 0) {
-        a.stamps[4 * blockIdx.x] = __builtin_amdgcn_s_memtime();
-        a.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        a.stamps[AR_STAMPS * blockIdx.x] = __builtin_amdgcn_s_memtime();
+        a.stamps[AR_STAMPS * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        a.stamps[AR_STAMPS * blockIdx.x + 4] = xcc;
+        a.stamps[AR_STAMPS * blockIdx.x + 5] = hw;
     }
+    int tr = 6; (void)tr;  // AR_TRACE: stamps 6.. = s_memtime after every pass / epilogue of wave 0
     ArPipe p{a.tiles, Bs, 0, a.n_tiles, wave, lane};
     ar_issue_tile(p, 0);
+#if AR_NBUF > 2
+    ar_issue_tile(p, 1);
+#endif
 
     // observation as the first B operand: x[m][k = 4 q + r], zero beyond obs_dim (clamped address, selected after the load)
     f32x4 xin;
@@ -176,20 +224,20 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
         //  register sets and the two LDS buffers are in the same phase at every pass boundary)
         ar_zero<16>(x);
         f32x4 xin2[2] = {xin, xin};
-        ar_pass<2>(p, xin2, x, l15, q);
+        ar_pass<2>(p, xin2, x, l15, q); AR_T();
 #pragma unroll
         for (int t = 0; t < 16; ++t) x[t] += ar_vec4(vec, t, q);
-        ar_layernorm<16>(x, vec + 256, vec + 512, q);
+        ar_layernorm<16>(x, vec + 256, vec + 512, q); AR_T();
     }
     for (int l = 0; l < a.n_layers; ++l) {
         const float* lv = vec + l * AR_LAYER_VEC;
         if (l > 0) {  // x = norm1(x + W_ov x + b_ov)
             f32x4 acc[16];
             ar_zero<16>(acc);
-            ar_pass<16>(p, x, acc, l15, q);
+            ar_pass<16>(p, x, acc, l15, q); AR_T();
 #pragma unroll
             for (int t = 0; t < 16; ++t) x[t] += acc[t] + ar_vec4(lv, t, q);
-            ar_layernorm<16>(x, lv + 256, lv + 512, q);
+            ar_layernorm<16>(x, lv + 256, lv + 512, q); AR_T();
         }
         // x = norm2(x + W2 gelu(W1 x + b1) + b2), the 512 hidden units in two halves: the hidden half never leaves registers
         f32x4 acc2[16];
@@ -198,33 +246,34 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
         for (int half = 0; half < 2; ++half) {
             f32x4 h[16];
             ar_zero<16>(h);
-            ar_pass<16>(p, x, h, l15, q);
+            ar_pass<16>(p, x, h, l15, q); AR_T();
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const f32x4 b4 = ar_vec4(lv + 768 + 256 * half, t, q);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[t][r] = gelu_f(h[t][r] + b4[r]);
             }
-            ar_pass<16>(p, h, acc2, l15, q);
+            AR_T();
+            ar_pass<16>(p, h, acc2, l15, q); AR_T();
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t) x[t] += acc2[t] + ar_vec4(lv + 1280, t, q);
-        ar_layernorm<16>(x, lv + 1536, lv + 1792, q);
+        ar_layernorm<16>(x, lv + 1536, lv + 1792, q); AR_T();
     }
     const float* tv = vec + a.n_layers * AR_LAYER_VEC;
-    ar_layernorm<16>(x, tv, tv + 256, q);  // feature_norm
+    ar_layernorm<16>(x, tv, tv + 256, q); AR_T();  // feature_norm
     // ---- policy head: 256 -> 512 GELU LayerNorm
     f32x4 pp[32];
     ar_zero<32>(pp);
-    ar_pass<16>(p, x, pp, l15, q);
-    ar_pass<16>(p, x, pp + 16, l15, q);
+    ar_pass<16>(p, x, pp, l15, q); AR_T();
+    ar_pass<16>(p, x, pp + 16, l15, q); AR_T();
 #pragma unroll
     for (int t = 0; t < 32; ++t) {
         const f32x4 b4 = ar_vec4(tv + 512, t, q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) pp[t][r] = gelu_f(pp[t][r] + b4[r]);
     }
-    ar_layernorm<32>(pp, tv + 1024, tv + 1536, q);
+    ar_layernorm<32>(pp, tv + 1024, tv + 1536, q); AR_T();
     // ---- 512 -> 512 GELU LayerNorm -> 2A outputs.  The LayerNorm and the output Linear are folded into running sums:
     //   out[o] = rstd (sum_n g_n gamma_n W[o,n] - mean sum_n gamma_n W[o,n]) + sum_n beta_n W[o,n] + b[o],  g = gelu(.)
     // so the second 512-wide activation is never held (one-pass variance E[g^2] - mean^2 on O(1) values)
@@ -233,7 +282,7 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
     for (int half = 0; half < 2; ++half) {
         f32x4 a2[16];
         ar_zero<16>(a2);
-        ar_pass<32>(p, pp, a2, l15, q);
+        ar_pass<32>(p, pp, a2, l15, q); AR_T();
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int tt = 16 * half + t;
@@ -267,8 +316,8 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
 #pragma unroll
     for (int o = 0; o < 4; ++o) out[o] = rstd * (d[o] - mean * gs[o]) + es[o] + tv[5632 + o];
     if (a.stamps && tid == 0) {
-        a.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
-        a.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+        a.stamps[AR_STAMPS * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
+        a.stamps[AR_STAMPS * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
     }
     // mean, clamped log_std, action = mean + exp(log_std) eps  (agent/...:224-225, 780-782, 789)
     if (q == 0 && row < a.M) {

@@ -1142,33 +1142,50 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
 // Diagnostics: in-kernel shader clock of the acting megakernel (guide: DVFS give-back item 6): Delta s_memtime / Delta
 // s_memrealtime x 100 MHz per workgroup, median over workgroups of the last of `launches` back-to-back launches.
 // out[0] = clock MHz, out[1] = median workgroup lifetime in us, out[2] = workgroups.  Synchronises.
-int tvc_debug_rows_clock(tvc_sac* h, const float* obs, int32_t n, int32_t launches, double* out, void* stream) {
-    if (!h || !obs || !out || n < 1 || launches < 1) return tvc::set_error(TVC_EINVAL, "bad argument");
+static int rows_probe(tvc_sac* h, const float* obs, int32_t n, int32_t launches, int32_t flags, std::vector<unsigned long long>& v,
+                      void* stream) {
+    if (!h || !obs || n < 1 || launches < 1) return tvc::set_error(TVC_EINVAL, "bad argument");
     if (!h->rows_ok) return tvc::set_error(TVC_EINVAL, "this handle does not use the row-owner acting kernel");
     TVC_HIP_CHECK(hipSetDevice(h->device));
     const int nwg = (n + 63) / 64, A = h->cfg.act_dim;
     unsigned long long* st = nullptr;
     float* act = nullptr;
-    TVC_HIP_CHECK(hipMalloc((void**)&st, (size_t)nwg * 4 * sizeof(unsigned long long)));
+    TVC_HIP_CHECK(hipMalloc((void**)&st, (size_t)nwg * AR_STAMPS * sizeof(unsigned long long)));
     if (hipMalloc((void**)&act, (size_t)n * A * sizeof(float)) != hipSuccess) { (void)hipFree(st); return tvc::set_error(TVC_ENOMEM, "hipMalloc failed"); }
     g_rows_stamps = st;
     int rc = 0;
-    for (int i = 0; i < launches && rc == 0; ++i) rc = tvc_sac_act(h, obs, n, nullptr, act, nullptr, nullptr, 0, stream);
+    for (int i = 0; i < launches && rc == 0; ++i) rc = tvc_sac_act(h, obs, n, nullptr, act, nullptr, nullptr, flags & 4, stream);
     g_rows_stamps = nullptr;
     hipError_t he = hipStreamSynchronize((hipStream_t)stream);
-    std::vector<unsigned long long> v((size_t)nwg * 4);
+    v.assign((size_t)nwg * AR_STAMPS, 0);
     if (rc == 0 && he == hipSuccess) he = hipMemcpy(v.data(), st, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     (void)hipFree(st); (void)hipFree(act);
     if (rc) return rc;
     if (he != hipSuccess) return tvc::set_error(TVC_EHIP, "rows clock probe failed: %s", hipGetErrorString(he));
+    return 0;
+}
+int tvc_debug_rows_clock(tvc_sac* h, const float* obs, int32_t n, int32_t launches, double* out, void* stream) {
+    if (!out) return tvc::set_error(TVC_EINVAL, "bad argument");
+    std::vector<unsigned long long> v;
+    if (int rc = rows_probe(h, obs, n, launches, 0, v, stream)) return rc;
+    const int nwg = (n + 63) / 64;
     std::vector<double> mhz, life;
     for (int b = 0; b < nwg; ++b) {
-        const double dc = (double)(v[4 * b + 2] - v[4 * b]), dr = (double)(v[4 * b + 3] - v[4 * b + 1]);
+        const double dc = (double)(v[AR_STAMPS * b + 2] - v[AR_STAMPS * b]), dr = (double)(v[AR_STAMPS * b + 3] - v[AR_STAMPS * b + 1]);
         if (dr > 0) { mhz.push_back(dc / dr * 100.0); life.push_back(dr / 100.0); }
     }
     if (mhz.empty()) return tvc::set_error(TVC_EHIP, "no stamps came back");
     std::sort(mhz.begin(), mhz.end()); std::sort(life.begin(), life.end());
     out[0] = mhz[mhz.size() / 2]; out[1] = life[life.size() / 2]; out[2] = (double)nwg;
+    return 0;
+}
+// ... and the raw stamps of the last launch: 6 x uint64 per workgroup {s_memtime, s_memrealtime (100 MHz) at start, the same at
+// the end, XCC_ID, HW_ID} into a HOST buffer of ceil(n / 64) * 6 entries; flags bit 2 as in tvc_sac_act.
+int tvc_debug_rows_stamps(tvc_sac* h, const float* obs, int32_t n, int32_t launches, int32_t flags, uint64_t* out_host, void* stream) {
+    if (!out_host) return tvc::set_error(TVC_EINVAL, "bad argument");
+    std::vector<unsigned long long> v;
+    if (int rc = rows_probe(h, obs, n, launches, flags, v, stream)) return rc;
+    for (size_t i = 0; i < v.size(); ++i) out_host[i] = v[i];
     return 0;
 }
 
