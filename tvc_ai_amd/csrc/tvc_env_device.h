@@ -529,7 +529,13 @@ template <bool DR, bool W10>
 __device__ __forceinline__ void load_regs(Regs& r, float (&hw)[12], const EnvBuf& b, int i) {
     const float4* c = b.cells + i;
     const size_t np = b.np;
-    float4 g0 = c[0], g1 = c[np], g2 = c[2 * np], g3 = c[3 * np], g4 = c[4 * np];
+    float4 g0 = c[0], g1 = c[np], g2 = c[2 * np], g3 = c[3 * np];
+    // cell group 4 is two float2 planes: {previous action} (every instantiation) and {mass scale, thrust scale} (DR only):
+    // the nominal kernel neither reads nor writes the second plane (16 B per env-step less than one float4 cell)
+    const float2* p4 = reinterpret_cast<const float2*>(b.cells + 4 * np);
+    const float2 pa = p4[i];
+    float4 g4 = make_float4(pa.x, pa.y, 1.0f, 1.0f);
+    if (DR) { const float2 mt = p4[np + i]; g4.z = mt.x; g4.w = mt.y; }
     r.px = g0.x; r.py = g0.y; r.pz = g0.z;
     r.qx = g1.x; r.qy = g1.y; r.qz = g1.z; r.qw = g1.w;
     r.vx = g2.x; r.vy = g2.y; r.vz = g2.z;
@@ -564,8 +570,12 @@ __device__ __forceinline__ void store_regs(const Regs& r, const float (&hw)[12],
     c[np] = make_float4(r.qx, r.qy, r.qz, r.qw);
     c[2 * np] = make_float4(r.vx, r.vy, r.vz, __uint_as_float(a1));
     c[3 * np] = make_float4(r.wx, r.wy, r.wz, __uint_as_float(r.episode));
-    c[4 * np] = make_float4(r.pa0, r.pa1, r.ms, r.ts);
-    if (DR) c[5 * np] = make_float4(r.cg, r.windx, r.windy, r.windz);
+    float2* p4 = reinterpret_cast<float2*>(b.cells + 4 * np);
+    p4[i] = make_float2(r.pa0, r.pa1);
+    if (DR) {
+        p4[np + i] = make_float2(r.ms, r.ts);
+        c[5 * np] = make_float4(r.cg, r.windx, r.windy, r.windz);
+    }
     if (W10) {
         if (ring_slot == 100) {
             c[6 * np] = make_float4(hw[0], hw[1], hw[2], hw[3]);
