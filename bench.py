@@ -36,7 +36,7 @@ MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak (= fp
 # Algorithmic bytes of one env-step through the single-step kernel (DESIGN.md "K1 traffic"):
 # reads  dyn 13 + prev_action 2 + aux 2 + episode 1 + reward window 10 + action 2        = 30 words
 # writes dyn 13 + prev_action 2 + aux 2 + episode 1 + window slot 1 + obs 10 + reward 1  = 30 words + 2 flag bytes
-# (the 16-byte-cell layout actually moves 136 B in + 142 B out = 278 B; PMC-confirmed, profiles/r01_b_*)
+# (the cell layout actually moves 128 B in + 134 B out = 262 B; PMC: profiles/pmc_traffic.json)
 ENV_STEP_BYTES = 30 * 4 + 30 * 4 + 2
 # domain-randomised instantiation: + the six per-episode parameters (mass / thrust scale, cg offset, wind xyz) READ each step
 # (they only change at a reset, so their write-back is not algorithmic); + 8 B when the episode statistics are on (running return)
