@@ -87,3 +87,17 @@ def test_bench_refuses_to_run_fewer_ranks_than_asked():
                        env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 2, (p.returncode, p.stderr[-500:])
     assert "refusing to run fewer ranks" in p.stderr and p.stdout.strip() == ""
+
+
+def test_bench_defaults_to_the_reference_reward_window_for_the_train_workload():
+    """the headline train line runs MultiObjectiveReward's diversity test over the reference's whole 1000-entry deque (env/...:221);
+    the 10-entry approximation is opt-in (--reward-window 10), physics-only lines keep it (they measure the W10 kernel)"""
+    import importlib.util
+    from types import SimpleNamespace
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.reward_window(SimpleNamespace(reward_window=0, exact_reward=False), "train") == 1000
+    assert b.reward_window(SimpleNamespace(reward_window=10, exact_reward=False), "train") == 10
+    assert b.reward_window(SimpleNamespace(reward_window=0, exact_reward=False), "physics") == 10
+    assert b.reward_window(SimpleNamespace(reward_window=10, exact_reward=True), "physics") == 1000

@@ -20,7 +20,7 @@ run --workload train --envs-per-gpu 4096 --steps 300 --warmup 30
 run --workload train --envs-per-gpu 8192 --steps 300 --warmup 30
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --dr-stage 0
-run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --exact-reward
+run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --reward-window 10
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --updates-per-step 2
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --updates-per-step 4
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --share-cus off

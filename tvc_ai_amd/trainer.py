@@ -287,8 +287,9 @@ def bench_train(args, world, rank, device, n_envs=None):
     if stage is not None:  # BASELINE configs[4]: full domain randomisation at a curriculum stage (config.yaml:236-286, 340-349)
         from .env import dr_from_yaml
         env_over = dr_from_yaml({}, stage)
-    if getattr(args, "exact_reward", False):
-        env_over["distinct_window"] = 1000
+    # reward-history window: the reference's whole 1000-entry deque (env/...:221) unless the approximate 10-entry mode is asked for
+    win = 1000 if getattr(args, "exact_reward", False) else int(getattr(args, "reward_window", 0) or 0)
+    env_over["distinct_window"] = win if win else 1000
     shipped = bool(getattr(args, "shipped_acting", False))
     utd = max(1, int(getattr(args, "updates_per_step", 1)))
     tr = VecTrainer(n, device=device, family=family, batch_size=256, replay_capacity=1_000_000, seed=42,
