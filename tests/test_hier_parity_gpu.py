@@ -34,11 +34,13 @@ def test_goal_policy_and_low_level_policy_match_reference_goldens():
     hp.close()
 
 
-def test_goal_draw_and_fused_act_path():
+@pytest.mark.parametrize("n", [8192, 16384])
+def test_goal_draw_and_fused_act_path(n):
+    """8192 rows: the fused Linear+LayerNorm acting kernels; 16384 rows: the one-launch row-owner kernel with its
+    SqueezeExcitation section (fc1 as one blocked tile, fc2 like the embedding) and the 14-wide [state | goal] input"""
     g, H, P, s, _ = hier_setup()
     d = torch.device("cuda:0")
-    hp = _policy(H, P, pe_rows=1, max_rows=8192)
-    n = 8192  # large enough for the fused Linear+LayerNorm acting kernels
+    hp = _policy(H, P, pe_rows=1, max_rows=n)
     gen = torch.Generator().manual_seed(3)
     big = torch.from_numpy(s).repeat(n // s.shape[0], 1) + 0.01 * torch.randn(n, 10, generator=gen)
     u = torch.rand(n, generator=gen)

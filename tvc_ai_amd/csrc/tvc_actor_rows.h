@@ -34,12 +34,15 @@ constexpr int AR_LAYER_VEC = 2048;  // floats per encoder layer in the vector se
 //   +0 feature_norm gamma  +256 beta  +512 head.0 bias (512)  +1024 head.2 gamma  +1536 head.2 beta  +2048 head.4 bias
 //   +2560 head.6 gamma  +3072 head.6 beta  +3584 head.8 weight [4][512] (rows >= 2A zero)  +5632 head.8 bias [4]
 constexpr int AR_TAIL_VEC = 5648;
+// SqueezeExcitation block of the hierarchical low-level policy (use_se), behind the tail: +0 fc1 bias (16)  +16 fc2 bias (256)
+constexpr int AR_SE_VEC = 272;
 
 struct ActRowsArgs {
     const float* obs; const float* eps;          // [M, obs_dim], [M, A] or nullptr (deterministic)
     float* act; float* mean; float* logstd;      // [M, A]; mean / logstd may be nullptr
     const float4* tiles; const float* vec;       // packed weights
     int M, obs_dim, A, clamp_act, n_layers, n_tiles;
+    int use_se;                  // SqueezeExcitation(256, reduction 16) between feature_norm and the head (agent/...:104-118, 206-209)
     unsigned long long* stamps;  // diagnostics (tvc_debug_rows_clock): per workgroup {s_memtime, s_memrealtime} at start and end, XCC_ID, HW_ID
 };
 
@@ -262,6 +265,38 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
     }
     const float* tv = vec + a.n_layers * AR_LAYER_VEC;
     ar_layernorm<16>(x, tv, tv + 256, q); AR_T();  // feature_norm
+    if (a.use_se) {  // x *= sigmoid(fc2(relu(fc1(x)))): pooling a [B, C, 1] tensor over its last axis is the identity
+        const float* sv = tv + AR_TAIL_VEC;
+        // fc1 (256 -> 16) as ONE tile: n-block kt of the image holds the 16 output rows' weights of k-tile kt, so the 64 MFMAs
+        // of the tile accumulate into a single 16 x 16 accumulator (out[m][4 q + r]); an all-zero tile keeps the ring's parity
+        f32x4 s4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            const float4* base = ar_next(p) + q * 256 + l15;
+#pragma unroll
+            for (int kt = 0; kt < 16; ++kt) {
+                const float4 w = base[kt * 16];
+                s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x[kt][0], s4, 0, 0, 0);
+                s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x[kt][1], s4, 0, 0, 0);
+                s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x[kt][2], s4, 0, 0, 0);
+                s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x[kt][3], s4, 0, 0, 0);
+            }
+            (void)ar_next(p);
+        }
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(sv + 4 * q);
+        f32x4 yy[2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yy[0][r] = fmaxf(s4[r] + b1[r], 0.0f);
+        yy[1] = yy[0];
+        f32x4 g[16];
+        ar_zero<16>(g);
+        ar_pass<2>(p, yy, g, l15, q);  // fc2 (16 -> 256): one zero-padded 16-deep tile + an all-zero one, like the embedding
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f32x4 b2 = ar_vec4(sv + 16, t, q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[t][r] *= 1.0f / (1.0f + __expf(-(g[t][r] + b2[r])));
+        }
+    }
     // ---- policy head: 256 -> 512 GELU LayerNorm
     f32x4 pp[32];
     ar_zero<32>(pp);
@@ -335,7 +370,8 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
 }
 
 // ------------------------------------------------------------------ weight packing
-struct PackTile { long src; int ld, k0, kvalid, from_ov; };   // src: float offset of W[n0][0] in the parameter / derived buffer
+struct PackTile { long src; int ld, k0, kvalid, from_ov, blocked; };   // src: float offset of W[n0][0] in the parameter / derived buffer;
+// blocked = 1: a 16-row matrix, n-block kt of the image = its 16 rows at k-tile kt (image[q][16 kt + j] = W[j][16 kt + 4 q ..])
 struct PackVec { long src; int dst, count, from_ov; };
 __global__ void __launch_bounds__(256) pack_actor_kernel(const float* __restrict__ P, const float* __restrict__ OV,
                                                          const PackTile* __restrict__ tiles, int n_tiles,
@@ -348,8 +384,8 @@ __global__ void __launch_bounds__(256) pack_actor_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int idx = j * 256 + tid, qq = idx >> 8, n = idx & 255;
-            const int k = t.k0 + 4 * qq;
-            const float* r = base + (long)n * t.ld;
+            const int k = t.blocked ? 16 * (n >> 4) + 4 * qq : t.k0 + 4 * qq;
+            const float* r = base + (long)(t.blocked ? (n & 15) : n) * t.ld;
             float v[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {

@@ -787,7 +787,7 @@ struct tvc_sac {
 // The acting megakernel covers the reference shapes with the embedding folded (PE(0) on every row): everything else keeps
 // the per-layer kernels.
 static bool rows_supported(const tvc_sac_cfg& c, const FoldInfo& f) {
-    return c.family == 0 && f.embed && !c.use_se && c.d_model == 256 && c.ff_dim == 512 && c.head1 == 512 && c.head2 == 512 &&
+    return c.family == 0 && f.embed && c.d_model == 256 && c.ff_dim == 512 && c.head1 == 512 && c.head2 == 512 &&
            2 * c.act_dim <= 4 && c.obs_dim <= 16 && f.layers == c.n_layers && c.pe_rows == 1;
 }
 static int rows_min_rows() {  // acting batches at least this large take the one-launch path (64 rows per workgroup)
@@ -805,7 +805,7 @@ static void rows_tables(const tvc_sac_cfg& c, const NetDef& actor, const FoldInf
     const int d = 256;
     const long ostride = (long)d * d + d;
     auto pass = [&](long src, int ld, int n0, int k0, int ktiles, int kvalid, int from_ov) {
-        for (int kt = 0; kt < ktiles; ++kt) tiles.push_back(PackTile{src + (long)n0 * ld, ld, k0 + 16 * kt, kvalid, from_ov});
+        for (int kt = 0; kt < ktiles; ++kt) tiles.push_back(PackTile{src + (long)n0 * ld, ld, k0 + 16 * kt, kvalid, from_ov, 0});
     };
     auto vec = [&](long src, int dst, int count, int from_ov) { vecs.push_back(PackVec{src, dst, count, from_ov}); };
     for (int l = 0; l < c.n_layers; ++l) {
@@ -832,6 +832,13 @@ static void rows_tables(const tvc_sac_cfg& c, const NetDef& actor, const FoldInf
     const int tv = c.n_layers * AR_LAYER_VEC;
     vec(off("feature_norm.weight"), tv, d, 0);
     vec(off("feature_norm.bias"), tv + 256, d, 0);
+    if (c.use_se) {  // SqueezeExcitation: fc1 [16][256] as one blocked tile + a zero tile (k0 beyond kvalid), fc2 [256][16] like the embedding
+        tiles.push_back(PackTile{off("se_block.fc1.weight"), d, 0, d, 0, 1});
+        tiles.push_back(PackTile{off("se_block.fc1.weight"), d, d, d, 0, 0});
+        pass(off("se_block.fc2.weight"), 16, 0, 0, 2, 16, 0);
+        vec(off("se_block.fc1.bias"), tv + AR_TAIL_VEC, 16, 0);
+        vec(off("se_block.fc2.bias"), tv + AR_TAIL_VEC + 16, d, 0);
+    }
     for (int half = 0; half < 2; ++half) pass(off("policy_head.0.weight"), d, 256 * half, 0, 16, d, 0);
     vec(off("policy_head.0.bias"), tv + 512, 512, 0);
     vec(off("policy_head.2.weight"), tv + 1024, 512, 0);
@@ -991,7 +998,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
         for (const PackVec& v : pvecs) h->rows_ok = h->rows_ok && v.src >= 0;
         for (const PackTile& t : ptiles) h->rows_ok = h->rows_ok && t.src >= 0;
         h->rows_tiles = (int)ptiles.size(); h->rows_vecs = (int)pvecs.size();
-        h->pack_floats = (long)h->rows_tiles * 4096 + (long)cfg->n_layers * AR_LAYER_VEC + AR_TAIL_VEC;
+        h->pack_floats = (long)h->rows_tiles * 4096 + (long)cfg->n_layers * AR_LAYER_VEC + AR_TAIL_VEC + (cfg->use_se ? AR_SE_VEC : 0);
         bytes += 2 * h->pack_floats * 4 + ptiles.size() * sizeof(PackTile) + pvecs.size() * sizeof(PackVec) + 2048;
     }
     hipError_t he = hipMalloc(&h->slab, bytes);
@@ -1111,7 +1118,7 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
         a.obs = obs; a.eps = eps; a.act = act; a.mean = mean; a.logstd = logstd;
         a.tiles = reinterpret_cast<const float4*>(pk); a.vec = pk + (long)h->rows_tiles * 4096;
         a.M = n; a.obs_dim = h->cfg.obs_dim; a.A = A; a.clamp_act = (flags & 1) ? 0 : 1;
-        a.n_layers = h->cfg.n_layers; a.n_tiles = h->rows_tiles; a.stamps = g_rows_stamps;
+        a.n_layers = h->cfg.n_layers; a.n_tiles = h->rows_tiles; a.stamps = g_rows_stamps; a.use_se = h->cfg.use_se;
         // flags bit 2 ("share the CUs"): 64 KB of unused dynamic LDS make the kernel fit once per CU instead of twice, which
         // leaves half of every CU's registers (and 64 KB of LDS) to whatever runs on other streams -- the ~100 small kernels of
         // a SAC update beside the acting pass.  Two workgroups per CU own every VGPR of the CU: faster alone (1.9 vs 2.4 ms at

@@ -143,7 +143,9 @@ class VecTrainer:
         raw = self.act_raw if self.safety is not None else self.act
         if self.hier is not None:
             self.u_goal.uniform_()
-            a, _, _, _ = self.hier.act(cur, self.eps_act, self.u_goal, clamp=self.safety is None)
+            share = self.share_cus and self._snapshot  # the never-trained hierarchy has no snapshot to read; the update runs beside it
+            a, _, _, _ = self.hier.act(cur, self.eps_act, self.u_goal, clamp=self.safety is None,
+                                       share_rows=self.share_rows if share else 0)
             raw.copy_(a)
         else:
             share = self.share_cus and self._snapshot
