@@ -421,7 +421,8 @@ def main():
     if rank == 0:
         try:
             if not args.loop_only:
-                out.update(roofline_report(args, workload, n, step_fn if workload == "physics" else None, dev_us_per_step, device))
+                out.update(roofline_report(args, workload, n, step_fn if workload == "physics" else None, dev_us_per_step, device,
+                                           extras=world == 1))
         except Exception as e:  # the headline line must survive a failure of the diagnostic legs
             out["roofline"] = {"error": f"{type(e).__name__}: {e}"}
         if args.cpu_seconds > 0 and world == 1 and not args.loop_only:  # rank 0 at N = 1 only
@@ -563,7 +564,9 @@ def _layer_kernel_roofline(L, n, device):
     return rep
 
 
-def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device):
+def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device, extras=True):
+    """`roofline` of the dominant kernel (+ the integrator's); extras = the diagnostic legs (learner alone, acting alone, hierarchical
+    path, N = 1 plumbing, integrator at 4 M envs): rank 0 of a single-rank run only, the other ranks of a multi-GPU job would wait."""
     rep = {}
     if workload == "physics":
         # the timed region holds exactly K launches of this one kernel: launch duration = HIP-event time / K
@@ -610,6 +613,8 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device)
             rep.update(_layer_kernel_roofline(L, n, device))
         rep["roofline_integrator"] = integrator_roofline(n, device, dr_stage=args.dr_stage, stats=args.dr_stage > 0,
                                                          window=reward_window(args, workload))
+        if not extras:
+            return rep
         # learner alone (no env stepping): back-to-back SAC updates at B = 256 on a fixed batch
         try:
             from tvc_ai_amd.agent import NativeSAC, sac_cfg
