@@ -14,6 +14,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// The update's ~100 short kernels run BESIDE the acting kernel (one acting wave per SIMD issuing MFMAs back to back): raised wave
+// priority lets their few instructions issue ahead of that stream instead of alternating with it (tools/step_events.py).
+#ifndef TVC_LEARNER_PRIORITY
+#define TVC_LEARNER_PRIORITY 3
+#endif
+#define TVC_LEARNER_PRIO() __builtin_amdgcn_s_setprio(TVC_LEARNER_PRIORITY)
+
 namespace tvcnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -654,6 +661,7 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& g, int bx, int by, l
 }
 template <bool A_KC, bool B_KC, bool FAST>
 __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g) {
+    TVC_LEARNER_PRIO();
     __shared__ float red[4][32 * 33];
     skinny_body<A_KC, B_KC, FAST>(g, blockIdx.x, blockIdx.y, blockIdx.z, red);
 }
@@ -666,6 +674,7 @@ struct GemmPair {
 };
 template <bool FAST>
 __global__ void __launch_bounds__(256) gemm_skinny_bwd_kernel(GemmPair p) {
+    TVC_LEARNER_PRIO();
     __shared__ float red[4][32 * 33];
     int b = blockIdx.x;
     if (b < p.nw) {
@@ -701,6 +710,7 @@ __device__ __forceinline__ float thin_x(const ThinArgs& a, const float* X, const
     return (k < a.K && row < a.M) ? v : 0.0f;
 }
 __global__ void __launch_bounds__(256) thin_fwd_kernel(ThinArgs a) {
+    TVC_LEARNER_PRIO();
     __shared__ float xs[THIN_ROWS][THIN_K];
     const int tid = threadIdx.x, n = blockIdx.y * 256 + tid, row0 = blockIdx.x * THIN_ROWS;
     const long z = blockIdx.z;
@@ -790,6 +800,7 @@ __global__ void __launch_bounds__(256) fold_embed_kernel(const float* __restrict
                                                          const float* __restrict__ pe0, const float* __restrict__ Wov,
                                                          const float* __restrict__ bov, float* __restrict__ Wout,
                                                          float* __restrict__ bout, int d, int obs) {
+    TVC_LEARNER_PRIO();
     // one workgroup per output row o; thread j carries W_ov[o, j] times row j of [W_e | be] (obs + 1 <= 17 values), then a
     // workgroup reduction per value
     __shared__ float part[4][THIN_K + 1];
@@ -822,6 +833,7 @@ __global__ void __launch_bounds__(256) fold_embed_kernel(const float* __restrict
 }
 // dW[n, k] = sum_m dZ[m, n] X[m, k]: 32 weight rows per workgroup, the 8 half-waves split the batch rows
 __global__ void __launch_bounds__(256) thin_wgrad_kernel(ThinArgs a) {
+    TVC_LEARNER_PRIO();
     __shared__ float xs[64][THIN_K];
     __shared__ float red[8][32][THIN_K + 1];
     const int tid = threadIdx.x, l = tid & 31, rg = tid >> 5;
@@ -868,6 +880,7 @@ __global__ void __launch_bounds__(256) thin_wgrad_kernel(ThinArgs a) {
 }
 // dX[m, k] = sum_n dZ[m, n] W[n, k]: one wave per row
 __global__ void __launch_bounds__(256) thin_dgrad_kernel(ThinArgs a) {
+    TVC_LEARNER_PRIO();
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.M) return;
     const long z = blockIdx.z;
@@ -919,6 +932,7 @@ struct LnArgs {
 };
 template <int VPL>  // values per lane = N / 64
 __global__ void __launch_bounds__(256) layernorm_fwd_kernel(LnArgs a) {
+    TVC_LEARNER_PRIO();
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.M) return;
     const long z = blockIdx.y;
@@ -1044,6 +1058,7 @@ struct LnBwdArgs {
 };
 template <int VPL>
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(LnBwdArgs a) {
+    TVC_LEARNER_PRIO();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long z = blockIdx.y;
     const float* gm = a.gamma + z * a.gP;
@@ -1146,6 +1161,7 @@ struct HeadArgs {
     long gX, gW, gB, gO;
 };
 __global__ void __launch_bounds__(256) head_fwd_kernel(HeadArgs a) {
+    TVC_LEARNER_PRIO();
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.M) return;
     const long z = blockIdx.y;
@@ -1174,6 +1190,7 @@ struct HeadBwdArgs {
     long gD, gX, gW, gB;
 };
 __global__ void __launch_bounds__(256) head_bwd_dx_kernel(HeadBwdArgs a) {
+    TVC_LEARNER_PRIO();
     const long z = blockIdx.y;
     const int row = blockIdx.x;
     const float* dO = a.dOut + z * a.gD + (long)row * a.NO;
@@ -1186,6 +1203,7 @@ __global__ void __launch_bounds__(256) head_bwd_dx_kernel(HeadBwdArgs a) {
     }
 }
 __global__ void __launch_bounds__(256) head_bwd_dw_kernel(HeadBwdArgs a) {
+    TVC_LEARNER_PRIO();
     // thread per (j, k), blockIdx.z = chunk of 32 rows; partial sums meet through float atomics
     const long z = blockIdx.y;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1215,6 +1233,7 @@ __global__ void __launch_bounds__(256) head_bwd_dw_kernel(HeadBwdArgs a) {
 // ------------------------------------------------------------------ optimiser
 // target = tau * online + (1 - tau) * target   (agent/...:1005-1010)
 __global__ void polyak_kernel(float* __restrict__ tgt, const float* __restrict__ src, long n, float tau) {
+    TVC_LEARNER_PRIO();
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
         tgt[i] = tau * src[i] + (1.0f - tau) * tgt[i];
 }

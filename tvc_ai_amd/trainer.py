@@ -11,6 +11,8 @@ resume a run exactly.
 import time
 from typing import Optional
 
+import os
+
 import torch
 
 from .agent import NativeSAC, ReplayBuffer, sac_cfg
@@ -50,7 +52,9 @@ class VecTrainer:
         self.share_rows = num_envs
         if self.share_cus and updates_per_step <= 1 and num_envs >= 32768 and (num_envs // 2) % 64 == 0:
             self.share_rows = num_envs // 2
-        self._side = torch.cuda.Stream(self.device)
+        # the learner's stream: high HIP priority + raised wave priority inside its kernels (TVC_LEARNER_PRIO): -4 % on the step at
+        # 2 and 4 updates per step, the update ends ~0.2 ms earlier at 1 (tools/ab_prio.sh)
+        self._side = torch.cuda.Stream(self.device, priority=int(os.environ.get("TVC_SIDE_PRIORITY", "-1")))
         self._fork = torch.cuda.Event()
         # intrinsic curiosity bonus of the reference's training env (scripts/train.py:318, env/...:496-502)
         self.curiosity = None
