@@ -82,9 +82,6 @@ __device__ __forceinline__ const float4* ar_next(ArPipe& p) {
     __builtin_amdgcn_sched_barrier(0);
     const float4* cur = p.Bs + (p.ti & 1) * AR_TILE_F4;
     if (p.ti + 1 < p.n_tiles) ar_issue_tile(p, p.ti + 1);
-#elif defined(AR_ABL) && AR_ABL == 3 // timing-only ablation: no weight copies at all (barrier kept)
-    __syncthreads();
-    const float4* cur = p.Bs + (p.ti & 1) * AR_TILE_F4;
 #elif AR_NBUF == 2
     __syncthreads();
     const float4* cur = p.Bs + (p.ti & 1) * AR_TILE_F4;
@@ -101,63 +98,51 @@ __device__ __forceinline__ const float4* ar_next(ArPipe& p) {
     p.ti += 1;
     return cur;
 }
-// 16 MFMAs of one fragment group: output tiles 4 g .. 4 g + 3 (acc points at the group), the four k-steps of the tile
-__device__ __forceinline__ void ar_mfma16(const float4 (&w)[4], const f32x4 xk, f32x4* __restrict__ acc) {
+// KT k-tiles of one Linear: acc[t] (t = 0..15: output features 16 t + 4 q + r of this lane's row) += W . x^T.
+// The weight fragments come in sets of TWO n-tiles (two ds_read_b128 = 8 registers, 8 MFMAs: the two tiles x the four k-steps); the
+// stream of sets is software-pipelined ACROSS tile boundaries with two register sets: the reads of set i + 1 are issued in the
+// middle of the MFMAs of set i (4 MFMAs, 2 reads, 4 MFMAs by sched_group_barrier: hipcc answers a fragment's first use with a full
+// lgkmcnt(0), so reads issued right before it would expose an LDS round trip), and the tile barrier sits between the loads of a
+// tile's last set and that set's MFMAs, so the first reads of the next tile are in flight while the matrix pipe still works on the
+// previous one.  (Sets of four n-tiles, 16 registers each: +2 % at one wave per SIMD, profiles/r02_c_actor_rows.md.)
+__device__ __forceinline__ void ar_mfma8(const float4 (&w)[2], const f32x4 xk, f32x4* __restrict__ acc) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
             const float wv = c == 0 ? w[j].x : (c == 1 ? w[j].y : (c == 2 ? w[j].z : w[j].w));
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv, xk[c], acc[j], 0, 0, 0);
         }
 }
-// the four weight fragments of group g: lane (l15, q) reads image[q][16 (4 g + j) + l15], conflict-free ds_read_b128
-__device__ __forceinline__ void ar_frag4(float4 (&w)[4], const float4* __restrict__ base, int g) {
-#if defined(AR_ABL) && AR_ABL == 2   // timing-only ablation: no LDS fragment reads (values made up in registers)
+__device__ __forceinline__ void ar_frag2(float4 (&w)[2], const float4* __restrict__ base, int hg) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float t = __builtin_bit_cast(float, (int)(long)base + g + j);
-        asm volatile("" : "+v"(t));
-        w[j] = make_float4(t, t, t, t);
-    }
-#else
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = base[(4 * g + j) * 16];
-#endif
+    for (int j = 0; j < 2; ++j) w[j] = base[(2 * hg + j) * 16];
 }
-// order inside one fragment group: 8 MFMAs, the 4 fragment reads of the NEXT group, 8 MFMAs -- the reads are then ~256 cycles old
-// when the next group's first MFMA waits for them (hipcc answers that use with a full lgkmcnt(0), so reads issued right before
-// it would expose an LDS round trip per group)
-#define AR_SCHED_GROUP()                                    \
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);      \
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0)
-// KT k-tiles of one Linear: acc[t] (t = 0..15: output features 16 t + 4 q + r of this lane's row) += W . x^T.
-// The fragment stream is software-pipelined ACROSS tile boundaries with two register sets: the reads of group i + 1 are issued
-// in the middle of the MFMAs of group i, and the tile barrier sits between the loads of a tile's last group and that group's
-// MFMAs, so the first reads of the next tile are in flight while the matrix pipe still works on the previous one.
+#define AR_SCHED_HALF()                                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0)
 template <int KT>
 __device__ __forceinline__ void ar_pass(ArPipe& p, const f32x4* __restrict__ x, f32x4* __restrict__ acc, int l15, int q) {
-    float4 wa[4], wb[4];
+    float4 wa[2], wb[2];
     const float4* base = ar_next(p) + q * 256 + l15;
-    ar_frag4(wa, base, 0);
+    ar_frag2(wa, base, 0);
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-        ar_frag4(wb, base, 1);
-        ar_mfma16(wa, x[kt], acc);
-        AR_SCHED_GROUP();
-        ar_frag4(wa, base, 2);
-        ar_mfma16(wb, x[kt], acc + 4);
-        AR_SCHED_GROUP();
-        ar_frag4(wb, base, 3);
-        ar_mfma16(wa, x[kt], acc + 8);
-        AR_SCHED_GROUP();
-        if (kt + 1 < KT) {
-            base = ar_next(p) + q * 256 + l15;
-            ar_frag4(wa, base, 0);
+#pragma unroll
+        for (int hp = 0; hp < 4; ++hp) {  // half-group pairs (2 hp, 2 hp + 1)
+            ar_frag2(wb, base, 2 * hp + 1);
+            ar_mfma8(wa, x[kt], acc + 4 * hp);
+            AR_SCHED_HALF();
+            if (hp < 3) {
+                ar_frag2(wa, base, 2 * hp + 2);
+            } else if (kt + 1 < KT) {
+                base = ar_next(p) + q * 256 + l15;
+                ar_frag2(wa, base, 0);
+            }
+            ar_mfma8(wb, x[kt], acc + 4 * hp + 2);
+            AR_SCHED_HALF();
         }
-        ar_mfma16(wb, x[kt], acc + 12);
-        AR_SCHED_GROUP();
     }
 }
 __device__ __forceinline__ f32x4 ar_vec4(const float* __restrict__ v, int t, int q) {
