@@ -55,14 +55,18 @@ struct ActRowsArgs {
 #endif
 struct ArPipe {
     const float4* tiles; float4* Bs;
-    int ti, n_tiles, wave, lane;
+    int ti, n_tiles;
+    int wave;        // wave index in the workgroup, wave-uniform (readfirstlane): LDS destinations and M0 stay in SGPRs
+    unsigned goff;   // this lane's byte offset inside a tile, (wave * 256 + lane) * 16: ONE 32-bit VGPR next to a scalar tile base
 };
 #ifndef AR_NBUF
 #define AR_NBUF 2   // LDS tile buffers: 2 = copy one tile ahead; 4 = copy two tiles ahead (experiment, profiles/r02_c_actor_rows.md)
 #endif
 __device__ __forceinline__ void ar_issue_tile(const ArPipe& p, int ti) {
     // 16 KB = 4 waves x 4 wave-instructions x 1 KB, lane-linear image: LDS byte i of the tile = global byte i
-    const float4* src = p.tiles + (long)ti * AR_TILE_F4 + p.wave * 256 + p.lane;
+    // scalar tile base + 32-bit lane offset (the saddr form of the load): a per-lane 64-bit address would be one more live VGPR
+    // pair in a kernel that sits at the register limit, and it was being spilled and reloaded once per tile
+    const char* src = reinterpret_cast<const char*>(p.tiles) + ((size_t)__builtin_amdgcn_readfirstlane(ti) << 14) + p.goff;
     float4* dst = p.Bs + (ti & (AR_NBUF - 1)) * AR_TILE_F4 + p.wave * 256;
     // one address pair; the four 1 KB pieces go through the instruction's immediate offset, which advances both the global and
     // the LDS address (checked by tools/micro/mfma_lds.hip) -- separate pointers cost an M0 write + readfirstlane per piece (-3 %)
@@ -191,7 +195,7 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
         a.stamps[AR_STAMPS * blockIdx.x + 5] = hw;
     }
     int tr = 6; (void)tr;  // AR_TRACE: stamps 6.. = s_memtime after every pass / epilogue of wave 0
-    ArPipe p{a.tiles, Bs, 0, a.n_tiles, wave, lane};
+    ArPipe p{a.tiles, Bs, 0, a.n_tiles, __builtin_amdgcn_readfirstlane(wave), (unsigned)((wave * 256 + lane) * 16)};
     ar_issue_tile(p, 0);
 #if AR_NBUF > 2
     ar_issue_tile(p, 1);
