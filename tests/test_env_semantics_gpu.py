@@ -171,3 +171,52 @@ def test_workgroups_are_dealt_round_robin_over_the_eight_xcds():
     assert set(xcc.tolist()) == set(range(8))
     assert (np.bincount(xcc, minlength=8) == nb // 8).all()
     assert (xcc[8:] == xcc[:-8]).mean() > 0.99   # same XCD every 8 blocks
+
+
+def test_exact_reward_history_under_wraparound_duplicates_and_import():
+    """distinct_window = 1000 keeps `distinct` (= len(set(deque)) of env/...:221) incrementally (one scan of the env's 1000-entry ring per
+    step).  Stress it where an incremental count could drift: the ring wraps (evictions), half of the envs replay the SAME episode
+    over and over (zero action, no randomisation: one reward value fills the ring), the state is exported and imported into a fresh
+    env, and both continue in lock step.  (A hashed count table that skips most scans was tried here and dropped: an untrained
+    policy's ring holds ~90 distinct values, so the table could rarely answer, and its scattered byte accesses cost more than the scan.)"""
+    from tvc_ai_amd import VecRocketTVCEnv
+    n, steps = 64, 1300
+    gen = torch.Generator().manual_seed(11)
+    env = VecRocketTVCEnv(n, device="cuda:0", contact=1, auto_reset=1, distinct_window=1000)
+    env.reset()
+    same = torch.arange(n) < n // 2
+
+    def action():
+        a = torch.rand((n, 2), generator=gen) * 2 - 1
+        a[same] = 0.0
+        return a.cuda()
+
+    def check(e):
+        st = e.export_state()
+        aux, hist = st["aux"].cpu().numpy(), st["hist"].cpu().numpy()
+        for i in range(n):
+            hl = int(aux[i, 4])
+            assert aux[i, 6] == len(set(hist[i, :hl].tolist())), (i, hl, aux[i, 6])
+        return aux
+
+    for t in range(steps):
+        env.step(action())
+        if t % 97 == 0 or t == steps - 1:
+            aux = check(env)
+    assert (aux[:, 4] == 1000).all()                       # the ring is full and has wrapped
+    # heavy duplication everywhere: the zero-action envs end up with ONE value 1000 times, the
+    # random ones with ~90 - 500 distinct values (crash penalties repeat)
+    assert aux[: n // 2, 6].max() < 200 and 1 <= aux[:, 6].min() and aux[:, 6].max() < 1000
+    st = env.export_state()
+    twin = VecRocketTVCEnv(n, device="cuda:0", contact=1, auto_reset=1, distinct_window=1000)
+    twin.reset()
+    twin.import_state(dyn=st["dyn"], aux=st["aux"], prev_action=st["prev_action"], params=st["params"], hist=st["hist"])
+    for t in range(120):
+        a = action()
+        o1, r1, te1, tr1, _ = env.step(a)
+        o2, r2, te2, tr2, _ = twin.step(a)
+        assert torch.equal(r1, r2) and torch.equal(o1, o2) and torch.equal(te1, te2) and torch.equal(tr1, tr2)
+    check(env)
+    check(twin)
+    env.close()
+    twin.close()
