@@ -116,11 +116,15 @@ class VecTrainer:
         self._cur_host = torch.zeros(4, dtype=torch.float64).pin_memory()
         self._cur_event = torch.cuda.Event()
         self._cur_pending = False
+        self._cur_req_step, self._cur_lag = 0, max(1, min(8, int(every) // 2))
         self._cur_last = [0.0, 0.0, 0.0, 0.0]
         self.curriculum_log = []
 
     def _curriculum_tick(self):
-        if self._cur_pending and self._cur_event.query():
+        # Read-back of a request made `lag` steps ago: a FIXED step distance (not "whenever the copy has landed"), so that with data
+        # parallelism every rank evaluates, and changes stage, at the same step; the copy landed long ago, the wait costs nothing.
+        if self._cur_pending and self.steps >= self._cur_req_step + self._cur_lag:
+            self._cur_event.synchronize()
             tot = self._cur_host.tolist()
             d = [a - b for a, b in zip(tot, self._cur_last)]
             if d[0] >= self._cur_min_eps:  # enough finished episodes for an evaluation (the reference evaluates 50, :success_criteria)
@@ -139,6 +143,7 @@ class VecTrainer:
             self._cur_host.copy_(tot, non_blocking=True)
             self._cur_event.record()
             self._cur_pending = True
+            self._cur_req_step = self.steps
 
     def collect(self):
         """act + env step + replay insert"""
