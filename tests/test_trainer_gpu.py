@@ -107,3 +107,36 @@ def test_checkpoint_resume_continues_the_same_run(tmp_path, shipped):
         c.close()
     a.close()
     b.close()
+
+
+def test_captured_step_replays_the_same_work_as_eager_steps():
+    """VecTrainer.capture(): whole train steps as one hipGraph.  Replaying must do what eager steps do: same number of transitions,
+    same Adam step counters, and -- same seeds, same draws from the device generator -- the same parameters up to the summation
+    order of the float atomics in the backward kernels (two eager runs differ by ~1e-5 as well)."""
+    from tvc_ai_amd.trainer import VecTrainer
+    n, B = 2048, 64
+    kw = dict(device="cuda:0", family=0, batch_size=B, replay_capacity=50_000, seed=5)
+
+    def run(graphed):
+        torch.manual_seed(123)  # the trainers draw their exploration / update noise from the default device generator
+        t = VecTrainer(n, **kw)
+        for _ in range(3):
+            t.step(True)
+        if graphed:
+            replay = t.capture(steps_per_replay=2)
+            for _ in range(5):
+                replay()
+        else:
+            for _ in range(10):
+                t.step(True)
+        torch.cuda.synchronize()
+        out = (t.steps, len(t.rb), t.sac.adam_steps(), t.sac.params.cpu().clone(), t.sac.losses.cpu().clone())
+        t.close()
+        return out
+
+    sa, ra, aa, pa, la = run(True)
+    sb, rb, ab, pb, lb = run(False)
+    assert sa == sb == 13 and ra == rb == min(50_000, 13 * n) and aa == ab
+    assert torch.isfinite(la).all() and torch.isfinite(lb).all()
+    assert (pa - pb).abs().max().item() < 1e-3, (pa - pb).abs().max().item()
+    torch.testing.assert_close(la, lb, rtol=1e-3, atol=1e-3)

@@ -225,6 +225,39 @@ class VecTrainer:
                 sac.update(s, a, r, s2, d, self.eps1[k], self.eps2[k], all_reduce=self.sync, grad_scale=gs)
         main.wait_stream(side)
 
+    def capture(self, steps_per_replay: int = 1):
+        """Capture `steps_per_replay` whole train steps (both streams, RNG draws included) in ONE hipGraph and return a function that
+        replays it: at small env counts the ~130 launches of a step cost the host more than the device (4 096 envs: 0.77 ms per step
+        replayed, 0.80 - 0.93 ms launched eagerly, profiles/r02_f_bench_matrix.md).  Single-rank only (the RCCL all-reduces of a
+        data-parallel update are not captured); the curriculum driver's host-side bookkeeping runs after every replay."""
+        if self.world > 1:
+            raise RuntimeError("VecTrainer.capture: single-rank only")
+        if int(steps_per_replay) % 2:
+            raise ValueError("VecTrainer.capture: an even number of steps per replay (the observation double buffer flips every step)")
+        if self.steps < 2:  # the overlapped schedule starts at the second step; warm every kernel up before capturing
+            for _ in range(2 - self.steps):
+                self.step(True)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        cap = torch.cuda.Stream(self.device)
+        cap.wait_stream(torch.cuda.current_stream(self.device))
+        steps0 = self.steps
+        with torch.cuda.stream(cap):
+            with torch.cuda.graph(graph, stream=cap):
+                for _ in range(int(steps_per_replay)):
+                    self.step(True)
+        torch.cuda.current_stream(self.device).wait_stream(cap)
+        self.steps = steps0  # capturing executed nothing
+
+        def replay():
+            graph.replay()
+            self.steps += int(steps_per_replay)
+            if self.curriculum is not None:
+                self._curriculum_tick()
+
+        replay.graph = graph
+        return replay
+
     # -- true resume (the reference's --resume is a stub, scripts/train.py:904-907): learner, env SoA state, current
     #    observations, replay contents and counters, and the device RNG state
     def state_dict(self):
