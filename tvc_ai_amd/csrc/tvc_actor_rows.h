@@ -149,6 +149,36 @@ __device__ __forceinline__ void ar_pass(ArPipe& p, const f32x4* __restrict__ x, 
         }
     }
 }
+// The same for a "deep" tile: 32 k x 128 outputs (two 8 KB halves, half a = k-steps 16 a .. 16 a + 15 of the 128 output rows), used
+// where only 128 outputs are wanted at a time: acc[t] (t = 0..7) += W[128 rows] . x^T over KT2 tiles = 32 KT2 inputs; the tile's
+// first half multiplies x[2 kt], its second half x[2 kt + 1], into the SAME eight accumulators.  64 MFMAs per tile as before.
+template <int KT2>
+__device__ __forceinline__ void ar_pass_q(ArPipe& p, const f32x4* __restrict__ x, f32x4* __restrict__ acc, int l15, int q) {
+    float4 wa[2], wb[2];
+    const float4* base = ar_next(p) + q * 128 + l15;
+    auto frag = [&](float4 (&w)[2], const float4* b, int s) {  // set s of a tile: half s / 4, n-tiles 2 (s % 4), 2 (s % 4) + 1
+#pragma unroll
+        for (int j = 0; j < 2; ++j) w[j] = b[(s >> 2) * 512 + (2 * (s & 3) + j) * 16];
+    };
+    frag(wa, base, 0);
+#pragma unroll
+    for (int kt = 0; kt < KT2; ++kt) {
+#pragma unroll
+        for (int hp = 0; hp < 4; ++hp) {  // sets 2 hp, 2 hp + 1
+            frag(wb, base, 2 * hp + 1);
+            ar_mfma8(wa, x[2 * kt + ((2 * hp) >> 2)], acc + 2 * ((2 * hp) & 3));
+            AR_SCHED_HALF();
+            if (hp < 3) {
+                frag(wa, base, 2 * hp + 2);
+            } else if (kt + 1 < KT2) {
+                base = ar_next(p) + q * 128 + l15;
+                frag(wa, base, 0);
+            }
+            ar_mfma8(wb, x[2 * kt + ((2 * hp + 1) >> 2)], acc + 2 * ((2 * hp + 1) & 3));
+            AR_SCHED_HALF();
+        }
+    }
+}
 __device__ __forceinline__ f32x4 ar_vec4(const float* __restrict__ v, int t, int q) {
     return *reinterpret_cast<const f32x4*>(v + 16 * t + 4 * q);
 }
@@ -231,22 +261,25 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
             for (int t = 0; t < 16; ++t) x[t] += acc[t] + ar_vec4(lv, t, q);
             ar_layernorm<16>(x, lv + 256, lv + 512, q); AR_T();
         }
-        // x = norm2(x + W2 gelu(W1 x + b1) + b2), the 512 hidden units in two halves: the hidden half never leaves registers
+        // x = norm2(x + W2 gelu(W1 x + b1) + b2), the 512 hidden units in four quarters of 128: a quarter of the hidden activation is
+        // 32 registers per lane, so x (64) + the output accumulators (64) + the quarter + the fragment sets stay clear of the
+        // 256-VGPR budget -- with halves the kernel spilled ~180 dwords per lane, and every spill is a round trip to the
+        // Infinity Cache (scratch is 190 MB at 65 536 rows: 0.5 GB of write-backs and as much reloaded per launch)
         f32x4 acc2[16];
         ar_zero<16>(acc2);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            f32x4 h[16];
-            ar_zero<16>(h);
-            ar_pass<16>(p, x, h, l15, q); AR_T();
+        for (int quarter = 0; quarter < 4; ++quarter) {
+            f32x4 h[8];
+            ar_zero<8>(h);
+            ar_pass_q<8>(p, x, h, l15, q); AR_T();
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const f32x4 b4 = ar_vec4(lv + 768 + 256 * half, t, q);
+            for (int t = 0; t < 8; ++t) {
+                const f32x4 b4 = ar_vec4(lv + 768 + 128 * quarter, t, q);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[t][r] = gelu_f(h[t][r] + b4[r]);
             }
             AR_T();
-            ar_pass<16>(p, h, acc2, l15, q); AR_T();
+            ar_pass<8>(p, h, acc2, l15, q); AR_T();
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t) x[t] += acc2[t] + ar_vec4(lv + 1280, t, q);
@@ -360,7 +393,8 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
 
 // ------------------------------------------------------------------ weight packing
 struct PackTile { long src; int ld, k0, kvalid, from_ov, blocked; };   // src: float offset of W[n0][0] in the parameter / derived buffer;
-// blocked = 1: a 16-row matrix, n-block kt of the image = its 16 rows at k-tile kt (image[q][16 kt + j] = W[j][16 kt + 4 q ..])
+// blocked = 1: a 16-row matrix, n-block kt of the image = its 16 rows at k-tile kt (image[q][16 kt + j] = W[j][16 kt + 4 q ..]);
+// blocked = 2: a deep tile, 32 k x 128 rows: image[a][q][n] = W[n][k0 + 16 a + 4 q ..] for n < 128
 struct PackVec { long src; int dst, count, from_ov; };
 __global__ void __launch_bounds__(256) pack_actor_kernel(const float* __restrict__ P, const float* __restrict__ OV,
                                                          const PackTile* __restrict__ tiles, int n_tiles,
@@ -373,8 +407,13 @@ __global__ void __launch_bounds__(256) pack_actor_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int idx = j * 256 + tid, qq = idx >> 8, n = idx & 255;
-            const int k = t.blocked ? 16 * (n >> 4) + 4 * qq : t.k0 + 4 * qq;
-            const float* r = base + (long)(t.blocked ? (n & 15) : n) * t.ld;
+            int k = t.k0 + 4 * qq, nrow = n;
+            if (t.blocked == 1) { k = 16 * (n >> 4) + 4 * qq; nrow = n & 15; }
+            if (t.blocked == 2) {  // deep tile: idx = a * 512 + q * 128 + n, 128 output rows, k0 + 16 a + 4 q
+                const int a = idx >> 9, rem = idx & 511;
+                k = t.k0 + 16 * a + 4 * (rem >> 7); nrow = rem & 127;
+            }
+            const float* r = base + (long)nrow * t.ld;
             float v[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {

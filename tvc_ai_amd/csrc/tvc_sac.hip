@@ -807,6 +807,10 @@ static void rows_tables(const tvc_sac_cfg& c, const NetDef& actor, const FoldInf
     auto pass = [&](long src, int ld, int n0, int k0, int ktiles, int kvalid, int from_ov) {
         for (int kt = 0; kt < ktiles; ++kt) tiles.push_back(PackTile{src + (long)n0 * ld, ld, k0 + 16 * kt, kvalid, from_ov, 0});
     };
+    // deep tiles (32 k x 128 output rows n0 .. n0 + 127), kt2 of them = 32 kt2 inputs
+    auto deep = [&](long src, int ld, int n0, int kt2, int kvalid) {
+        for (int kt = 0; kt < kt2; ++kt) tiles.push_back(PackTile{src + (long)n0 * ld, ld, 32 * kt, kvalid, 0, 2});
+    };
     auto vec = [&](long src, int dst, int count, int from_ov) { vecs.push_back(PackVec{src, dst, count, from_ov}); };
     for (int l = 0; l < c.n_layers; ++l) {
         const std::string p = "layers." + std::to_string(l) + ".";
@@ -820,9 +824,9 @@ static void rows_tables(const tvc_sac_cfg& c, const NetDef& actor, const FoldInf
         }
         vec(off(p + "norm1.weight"), lv + 256, d, 0);
         vec(off(p + "norm1.bias"), lv + 512, d, 0);
-        for (int half = 0; half < 2; ++half) {
-            pass(off(p + "linear1.weight"), d, 256 * half, 0, 16, d, 0);       // hidden units [256 half, +256) <- x
-            pass(off(p + "linear2.weight"), 512, 0, 256 * half, 16, 512, 0);   // out += W2[:, hidden half] h
+        for (int quarter = 0; quarter < 4; ++quarter) {
+            deep(off(p + "linear1.weight"), d, 128 * quarter, 8, d);              // hidden units [128 quarter, +128) <- x: 8 deep tiles
+            pass(off(p + "linear2.weight"), 512, 0, 128 * quarter, 8, 512, 0);    // out += W2[:, hidden quarter] h
         }
         vec(off(p + "linear1.bias"), lv + 768, 512, 0);
         vec(off(p + "linear2.bias"), lv + 1280, d, 0);
