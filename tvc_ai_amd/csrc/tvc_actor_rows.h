@@ -32,7 +32,8 @@ constexpr int AR_LAYER_VEC = 2048;  // floats per encoder layer in the vector se
 //   +768 linear1 bias (512)   +1280 linear2 bias   +1536 norm2 gamma   +1792 norm2 beta
 // tail at n_layers * AR_LAYER_VEC:
 //   +0 feature_norm gamma  +256 beta  +512 head.0 bias (512)  +1024 head.2 gamma  +1536 head.2 beta  +2048 head.4 bias
-//   +2560 head.6 gamma  +3072 head.6 beta  +3584 head.8 weight [4][512] (rows >= 2A zero)  +5632 head.8 bias [4]
+//   +2560 head.6 gamma  +3072 head.6 beta  +3584 gamma6 x head.8 weight [4][512] (rows >= 2A zero)  +5632 E[4]  +5636 G[4]
+//   (pack_head_kernel: the input-independent parts of the folded LayerNorm + output Linear)
 constexpr int AR_TAIL_VEC = 5648;
 // SqueezeExcitation block of the hierarchical low-level policy (use_se), behind the tail: +0 fc1 bias (16)  +16 fc2 bias (256)
 constexpr int AR_SE_VEC = 272;
@@ -333,8 +334,9 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
     ar_layernorm<32>(pp, tv + 1024, tv + 1536, q); AR_T();
     // ---- 512 -> 512 GELU LayerNorm -> 2A outputs.  The LayerNorm and the output Linear are folded into running sums:
     //   out[o] = rstd (sum_n g_n gamma_n W[o,n] - mean sum_n gamma_n W[o,n]) + sum_n beta_n W[o,n] + b[o],  g = gelu(.)
+    // (gamma_n W[o,n] and the two input-independent sums come ready-made from pack_head_kernel)
     // so the second 512-wide activation is never held (one-pass variance E[g^2] - mean^2 on O(1) values)
-    float s1 = 0.0f, s2 = 0.0f, d[4] = {0.f, 0.f, 0.f, 0.f}, gs[4] = {0.f, 0.f, 0.f, 0.f}, es[4] = {0.f, 0.f, 0.f, 0.f};
+    float s1 = 0.0f, s2 = 0.0f, d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         f32x4 a2[16];
@@ -343,35 +345,30 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int tt = 16 * half + t;
-            const f32x4 b4 = ar_vec4(tv + 2048, tt, q), g4 = ar_vec4(tv + 2560, tt, q), be4 = ar_vec4(tv + 3072, tt, q);
-            f32x4 wh[4];
+            const f32x4 b4 = ar_vec4(tv + 2048, tt, q);
+            f32x4 gw[4];  // gamma6[n] W8[o][n], made by pack_head_kernel
 #pragma unroll
-            for (int o = 0; o < 4; ++o) wh[o] = ar_vec4(tv + 3584 + 512 * o, tt, q);
+            for (int o = 0; o < 4; ++o) gw[o] = ar_vec4(tv + 3584 + 512 * o, tt, q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = gelu_f(a2[t][r] + b4[r]);
                 s1 += v;
                 s2 = fmaf(v, v, s2);
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    const float gw = g4[r] * wh[o][r];
-                    d[o] = fmaf(v, gw, d[o]);
-                    gs[o] += gw;
-                    es[o] = fmaf(be4[r], wh[o][r], es[o]);
-                }
+                for (int o = 0; o < 4; ++o) d[o] = fmaf(v, gw[o][r], d[o]);
             }
         }
     }
 #define AR_RED(v) v += __shfl_xor(v, 16); v += __shfl_xor(v, 32)
     AR_RED(s1); AR_RED(s2);
 #pragma unroll
-    for (int o = 0; o < 4; ++o) { AR_RED(d[o]); AR_RED(gs[o]); AR_RED(es[o]); }
+    for (int o = 0; o < 4; ++o) { AR_RED(d[o]); }
 #undef AR_RED
     const float mean = s1 * (1.0f / 512.0f);
     const float rstd = rsqrtf(fmaxf(s2 * (1.0f / 512.0f) - mean * mean, 0.0f) + 1e-5f);
     float out[4];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) out[o] = rstd * (d[o] - mean * gs[o]) + es[o] + tv[5632 + o];
+    for (int o = 0; o < 4; ++o) out[o] = rstd * (d[o] - mean * tv[5636 + o]) + tv[5632 + o];
     if (a.stamps && tid == 0) {
         a.stamps[AR_STAMPS * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
         a.stamps[AR_STAMPS * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
@@ -426,6 +423,35 @@ __global__ void __launch_bounds__(256) pack_actor_kernel(const float* __restrict
         const PackVec e = vecs[b - n_tiles];
         const float* src = (e.from_ov ? OV : P) + e.src;
         for (int i = tid; i < e.count; i += 256) out_vec[e.dst + i] = src[i];
+    }
+}
+
+// The output head behind the second LayerNorm of the policy head is folded into running sums (actor_rows_body): the parts of that
+// fold that do not depend on the input are made here, once per policy update, into the vector tail:
+//   +3584  gW[o][n] = gamma6[n] W8[o][n]   (o < 2A, else 0)      +5632  E[o] = sum_n beta6[n] W8[o][n] + b8[o]      +5636  G[o] = sum_n gW[o][n]
+__global__ void __launch_bounds__(256) pack_head_kernel(const float* __restrict__ gamma6, const float* __restrict__ beta6,
+                                                        const float* __restrict__ W8, const float* __restrict__ b8, int n_out,
+                                                        float* __restrict__ tail) {
+    __shared__ float red[2][4][256];
+    const int tid = threadIdx.x;
+    for (int o = 0; o < 4; ++o) {
+        float g = 0.0f, e = 0.0f;
+        for (int n = tid; n < 512; n += 256) {
+            const float w = o < n_out ? W8[o * 512 + n] : 0.0f;
+            const float gw = gamma6[n] * w;
+            tail[3584 + 512 * o + n] = gw;
+            g += gw;
+            e = fmaf(beta6[n], w, e);
+        }
+        red[0][o][tid] = g; red[1][o][tid] = e;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        const int o = tid & 3, which = tid >> 2;
+        float s = 0.0f;
+        for (int i = 0; i < 256; ++i) s += red[which][o][i];
+        if (which == 0) tail[5636 + o] = s;
+        else tail[5632 + o] = s + (o < n_out ? b8[o] : 0.0f);
     }
 }
 

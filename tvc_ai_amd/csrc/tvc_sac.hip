@@ -764,6 +764,7 @@ struct tvc_sac {
     Ctx actx, cctx, ictx;                      // actor (train), critics (train, G=2), actor (inference, slot-aliased)
     Ctx dctx;                                  // actor as trained (unfolded, dropout sites), slot-aliased: acting in train mode
     bool dctx_ok = false;
+    long head_off[4] = {0, 0, 0, 0};           // policy_head.6 weight / bias, policy_head.8 weight / bias (pack_head_kernel)
     int* act_ctr = nullptr;                    // dropout counter of the train-mode acting calls (advanced by each call)
     float *xs2 = nullptr;   // [2B, obs]: states and next states stacked for the single actor forward of an update
     bool actor_fwd_valid = false;
@@ -849,10 +850,7 @@ static void rows_tables(const tvc_sac_cfg& c, const NetDef& actor, const FoldInf
     vec(off("policy_head.2.bias"), tv + 1536, 512, 0);
     for (int half = 0; half < 2; ++half) pass(off("policy_head.4.weight"), 512, 256 * half, 0, 32, 512, 0);
     vec(off("policy_head.4.bias"), tv + 2048, 512, 0);
-    vec(off("policy_head.6.weight"), tv + 2560, 512, 0);
-    vec(off("policy_head.6.bias"), tv + 3072, 512, 0);
-    vec(off("policy_head.8.weight"), tv + 3584, 2 * c.act_dim * 512, 0);      // rows >= 2A stay zero (the slab is zero-filled)
-    vec(off("policy_head.8.bias"), tv + 5632, 2 * c.act_dim, 0);
+    // policy_head.6 (LayerNorm) and policy_head.8 (output Linear) enter the tail through pack_head_kernel, already folded
 }
 
 static long ctx_bytes(const NetDef& nd, int M, int G, bool train) {
@@ -999,6 +997,13 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     h->rows_ok = rows_supported(*cfg, h->fold);
     if (h->rows_ok) {
         rows_tables(*cfg, h->actor, h->fold, ptiles, pvecs);
+        const char* hn[4] = {"policy_head.6.weight", "policy_head.6.bias", "policy_head.8.weight", "policy_head.8.bias"};
+        for (int k = 0; k < 4; ++k) {
+            h->head_off[k] = -1;
+            for (const TensorInfo& t : h->actor.tensors)
+                if (t.name == hn[k]) h->head_off[k] = t.off;
+            h->rows_ok = h->rows_ok && h->head_off[k] >= 0;
+        }
         for (const PackVec& v : pvecs) h->rows_ok = h->rows_ok && v.src >= 0;
         for (const PackTile& t : ptiles) h->rows_ok = h->rows_ok && t.src >= 0;
         h->rows_tiles = (int)ptiles.size(); h->rows_vecs = (int)pvecs.size();
@@ -1343,9 +1348,14 @@ static void refresh_folded(tvc_sac* h, hipStream_t st) {
         hipLaunchKernelGGL(fold_embed_kernel, dim3(d), dim3(256), 0, st, h->P_actor() + f.e_w,
                            h->P_actor() + f.e_b, h->cfg.family == 0 ? h->pe : nullptr, h->ov, h->ov + (long)d * d, h->ov + f.e_off,
                            h->ov + f.e_off + (long)d * f.obs, d, f.obs);
-    if (h->rows_ok)  // re-pack the acting megakernel's weight stream from the fresh parameters / folded weights
+    if (h->rows_ok) {  // re-pack the acting megakernel's weight stream from the fresh parameters / folded weights
         hipLaunchKernelGGL(pack_actor_kernel, dim3(h->rows_tiles + h->rows_vecs), dim3(256), 0, st, h->P_actor(), h->ov, h->d_ptiles,
                            h->rows_tiles, h->d_pvecs, reinterpret_cast<float4*>(h->pack), h->pack + (long)h->rows_tiles * 4096);
+        const float* P = h->P_actor();
+        hipLaunchKernelGGL(pack_head_kernel, dim3(1), dim3(256), 0, st, P + h->head_off[0], P + h->head_off[1], P + h->head_off[2],
+                           P + h->head_off[3], 2 * h->cfg.act_dim,
+                           h->pack + (long)h->rows_tiles * 4096 + (long)h->cfg.n_layers * AR_LAYER_VEC);
+    }
 }
 
 // Adam step counters (critics, actor) live on the device so that a captured update keeps counting; these two calls
