@@ -208,6 +208,9 @@ __device__ __forceinline__ void ar_layernorm(f32x4* __restrict__ u, const float*
         const f32x4 g4 = ar_vec4(gamma, t, q), b4 = ar_vec4(beta, t, q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) u[t][r] = (u[t][r] - mean) * rstd * g4[r] + b4[r];
+        // the 512-wide norm holds 128 registers of activation: without a fence every 8 tiles hipcc hoists all 64 vector loads
+        // (256 more registers) and spills half the activation around them
+        if (NT > 16 && (t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -330,6 +333,7 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
         const f32x4 b4 = ar_vec4(tv + 512, t, q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) pp[t][r] = gelu_f(pp[t][r] + b4[r]);
+        if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
     ar_layernorm<32>(pp, tv + 1024, tv + 1536, q); AR_T();
     // ---- 512 -> 512 GELU LayerNorm -> 2A outputs.  The LayerNorm and the output Linear are folded into running sums:
