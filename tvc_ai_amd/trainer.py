@@ -40,6 +40,9 @@ class VecTrainer:
         self.rb = ReplayBuffer(replay_capacity, 10, 2, device=self.device, seed=seed * 1000003 + rank)
         self.sync = GradSync() if world > 1 else None
         self.overlap = overlap
+        # defer_join = True: a step returns without waiting for its update on the learner's stream (the next step waits before it
+        # takes its snapshot); whoever reads learner state in between synchronises the device first (state_dict() does)
+        self.defer_join = False
         # acting kernel placement (tvc_sac_act flags bit 2): alone on the chip it is fastest with two workgroups per CU, which
         # own every register of the CU -- the update then runs AFTER the acting pass.  One workgroup per CU is ~25 % slower
         # alone but lets the update's kernels run BESIDE it, which wins at every update count (65 536 envs: 2.49 vs 2.58 ms per
@@ -80,10 +83,12 @@ class VecTrainer:
         self.ls = torch.empty((n, 2), device=d)
         self.eps_act = torch.empty((n, 2), device=d)
         K = max(1, updates_per_step)
-        self.eps1 = [torch.empty((B, 2), device=d) for _ in range(K)]
-        self.eps2 = [torch.empty((B, 2), device=d) for _ in range(K)]
-        self.batches = [(torch.empty((B, 10), device=d), torch.empty((B, 2), device=d), torch.empty((B,), device=d),
-                         torch.empty((B, 10), device=d), torch.empty((B,), device=d)) for _ in range(K)]
+        # two sets of update inputs (batches + noise), alternating by step parity: the overlapped schedule draws the inputs of step
+        # t + 1 while the update of step t may still be reading its own
+        self._sets = [{"eps1": [torch.empty((B, 2), device=d) for _ in range(K)], "eps2": [torch.empty((B, 2), device=d) for _ in range(K)],
+                       "batches": [(torch.empty((B, 10), device=d), torch.empty((B, 2), device=d), torch.empty((B,), device=d),
+                                    torch.empty((B, 10), device=d), torch.empty((B,), device=d)) for _ in range(K)]} for _ in range(2)]
+        self.eps1, self.eps2, self.batches = self._sets[0]["eps1"], self._sets[0]["eps2"], self._sets[0]["batches"]
         self.batch = self.batches[0]
         self._snapshot = False  # collect() acts with the policy snapshot (overlapped schedule)
         self.curriculum = None
@@ -94,6 +99,7 @@ class VecTrainer:
         self.steps = 0
 
     def close(self):
+        torch.cuda.synchronize(self.device)  # the learner's stream may still be running the last update
         self.env.close()
         self.sac.close()
         self.rb.close()
@@ -187,6 +193,8 @@ class VecTrainer:
         if learn and self.overlap and self.steps > 0:
             self._step_overlapped()
         else:
+            if self.defer_join:
+                torch.cuda.current_stream(self.device).wait_stream(self._side)
             self.collect()
             if learn:
                 for k in range(self.updates_per_step):
@@ -204,10 +212,15 @@ class VecTrainer:
         transitions are inserted (no read of a row that is being overwritten)."""
         main = torch.cuda.current_stream(self.device)
         sac, side = self.sac, self._side
+        cur = self._sets[self.steps & 1]  # this step's update inputs; the previous update may still be reading the other set
+        batches, eps1, eps2 = cur["batches"], cur["eps1"], cur["eps2"]
         for k in range(self.updates_per_step):
-            self.rb.sample(self.B, out=self.batches[k])
-            self.eps1[k].normal_()
-            self.eps2[k].normal_()
+            self.rb.sample(self.B, out=batches[k])
+            eps1[k].normal_()
+            eps2[k].normal_()
+        # defer_join: the streams meet HERE, not at the end of the previous step: the tail of the previous update (it needs a little
+        # longer than the acting launch it runs beside) overlaps the env step, the replay insert and the draws above
+        main.wait_stream(side)
         sac.snapshot_policy()
         gs = self.sync.grad_scale if self.sync is not None else 1.0
         self._fork.record(main)
@@ -221,9 +234,10 @@ class VecTrainer:
         side.wait_event(self._fork)
         with torch.cuda.stream(side):
             for k in range(self.updates_per_step):
-                s, a, r, s2, d = self.batches[k]
-                sac.update(s, a, r, s2, d, self.eps1[k], self.eps2[k], all_reduce=self.sync, grad_scale=gs)
-        main.wait_stream(side)
+                s, a, r, s2, d = batches[k]
+                sac.update(s, a, r, s2, d, eps1[k], eps2[k], all_reduce=self.sync, grad_scale=gs)
+        if not self.defer_join or torch.cuda.is_current_stream_capturing():
+            main.wait_stream(side)  # (a captured graph must end with every forked stream joined)
 
     def capture(self, steps_per_replay: int = 1):
         """Capture `steps_per_replay` whole train steps (both streams, RNG draws included) in ONE hipGraph and return a function that
@@ -340,6 +354,7 @@ def bench_train(args, world, rank, device, n_envs=None):
                     rank=rank, world=world, updates_per_step=utd, overlap=not getattr(args, "no_overlap", False),
                     share_cus={"auto": None, "on": True, "off": False}[getattr(args, "share_cus", "auto")],
                     enable_hierarchical=shipped, enable_safety=shipped, enable_curiosity=shipped, **env_over)
+    tr.defer_join = True  # the bench synchronises the device around its timed region
     if stage is not None:  # the curriculum driver reads device-side episode statistics and owns the stage from here on
         from .curriculum import CurriculumDriver
         from .env import default_curriculum_config
