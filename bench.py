@@ -68,6 +68,14 @@ def parse():
     ap.add_argument("--exact-reward", action="store_true", help="alias of --reward-window 1000")
     ap.add_argument("--share-cus", choices=["auto", "on", "off"], default="auto",
                     help="train: one acting workgroup per CU so that the update runs beside the acting pass (auto: on with the two-stream schedule)")
+    ap.add_argument("--share-rows", type=int, default=-1, help="train: rows the acting kernel handles in its CU-sharing form; -1 = "
+                                                               "chosen at warm-up from measured step times (max over ranks)")
+    ap.add_argument("--segments", choices=["auto", "on", "off"], default="auto",
+                    help="train: replay the step as segment graphs between the update's collectives (auto: on with --gpus > 1, where "
+                         "a whole-step graph cannot hold the RCCL calls)")
+    ap.add_argument("--acting-dropout", action="store_true", help="train: act in train mode like the reference's get_action "
+                                                                  "(Dropout(0.1) live in the policy, agent/...:765)")
+    ap.add_argument("--no-shard-sizes", action="store_true", help="skip the extra 4 096 / 8 192-env legs (BASELINE's per-GPU shards)")
     ap.add_argument("--no-overlap", action="store_true", help="train: run the update after the acting pass instead of beside it")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one hipGraph per K steps")
     ap.add_argument("--graph", action="store_true", help="train: capture the K steps in one hipGraph (default: eager; the host "
@@ -368,6 +376,12 @@ def main():
     # multi-GPU train: the two gradient all-reduces (RCCL) sit between kernel phases; they are issued eagerly
     # rather than captured (collective capture is not something a 1-GPU gpurun box can validate)
     use_graph = (not args.no_graph) and (workload == "physics" or (args.graph and world == 1))
+    launch_mode = "hipGraph of K steps" if use_graph else "eager launches"
+    if workload == "train" and not use_graph and (args.segments == "on" or (args.segments == "auto" and world > 1)) \
+            and tr.updates_per_step == 1:
+        seg = tr.capture_segments()  # 4 graph launches + the 2 collectives per step instead of ~130 kernel launches
+        step_fn = lambda k: seg()
+        launch_mode = "segment graphs between the update's collectives (4 graph launches per step)"
     dt, dev_us_per_step, captured = timed_steps(step_fn, K, W, world, device, use_graph)
 
     env_steps = float(n) * world * K
@@ -391,7 +405,7 @@ def main():
         "config": {"workload": f"{workload}: {n} envs/GPU x {world} GPU(s) = {n * world} envs ({mode}), contact + auto-reset, "
                                f"reward-history window {reward_window(args, workload)}"
                                f"{' (the reference deque, env/...:221)' if reward_window(args, workload) == 1000 else ' (approximate throughput mode)'}, "
-                               f"{'hipGraph of K steps' if captured else 'eager launches'}",
+                               f"{launch_mode if (captured or not use_graph) else 'eager launches'}",
                    "envs_per_gpu": n, "total_envs": n * world, "reward_window": reward_window(args, workload)},
     }
     if workload == "train":
@@ -418,6 +432,15 @@ def main():
         except Exception as e:
             out["strong_scaling"] = {"error": f"{type(e).__name__}: {e}"}
 
+    if workload == "train" and world == 1 and not args.loop_only and not args.no_shard_sizes:
+        # BASELINE configs[2-4] put 4 096 - 8 192 envs on a GPU: the same loop at those sizes (they bound the strong-scaling curve)
+        try:
+            tr.close()
+            tr = None
+            out["shard_sizes"] = shard_sizes(args, device)
+        except Exception as e:
+            out["shard_sizes"] = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         try:
             if not args.loop_only:
@@ -435,6 +458,32 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def shard_sizes(args, device, sizes=(4096, 8192), K=200, W=30):
+    """ms per step / SAC updates per s of the train workload at BASELINE's per-GPU shard sizes, single rank, in the launch mode a
+    multi-rank job uses (segment graphs) and as eager launches."""
+    from tvc_ai_amd import trainer
+    rep = {}
+    for n in sizes:
+        ent = {}
+        for mode in ("segment_graphs", "eager"):
+            res = trainer.bench_train(args, 1, 0, device, n_envs=n)
+            t = res["trainer"]
+            fn = res["step_fn"]
+            if mode == "segment_graphs":
+                seg = t.capture_segments()
+                fn = lambda k: seg()
+            dt, _, _ = timed_steps(fn, K, W, 1, device, False)
+            ent[mode] = {"ms_per_step": dt / K * 1e3, "sac_updates_per_s": K / dt, "env_steps_per_s": n * K / dt}
+            if t.share_tuning is not None:
+                ent["share_rows"] = t.share_rows
+            t.close()
+        best = min(("segment_graphs", "eager"), key=lambda m: ent[m]["ms_per_step"])
+        rep[str(n)] = {"ms_per_step": ent[best]["ms_per_step"], "sac_updates_per_s": ent[best]["sac_updates_per_s"],
+                       "env_steps_per_s": ent[best]["env_steps_per_s"], "mode": best, **ent}
+    rep["note"] = f"same workload as the headline line (DR stage, reward window, update in the loop), {K} timed steps after {W}"
+    return rep
 
 
 def graph_time_us(fn, reps, device, rounds=5):
@@ -464,28 +513,44 @@ def graph_time_us(fn, reps, device, rounds=5):
 
 
 PMC_FILE = "profiles/pmc_traffic.json"
-LOOP_STATS_FILE = "profiles/r02_train_loop_kernel_stats.json"
+LOOP_STATS_FILE = "profiles/r03_train_loop_kernel_stats.json"
+STALE = {}  # what pmc_traffic() / in_loop_us() last answered -> was it taken at another build of the library than the one running
+
+
+def _lib_sha():
+    from tvc_ai_amd.build import sources_sha256
+    try:
+        return sources_sha256()
+    except Exception:
+        return None
 
 
 def pmc_traffic(n, kernel="env_step_kernel"):
     """HBM bytes per launch from the COMMITTED rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, both in
     KiB; tools/pmc_to_json.py), keyed by kernel and grid size in threads; None when that size was not profiled.
-    Not measured in this run: the JSON line labels it with `traffic_source`."""
+    Not measured in this run: the JSON line labels it with `traffic_source`, and with `traffic_stale` when the pass was taken at
+    other library sources than the ones running (sha256 stored by the tool)."""
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
-            return json.load(f).get(kernel, {}).get(str(n), {}).get("hbm_bytes_per_launch")
+            ent = json.load(f).get(kernel, {}).get(str(n), {})
+        STALE["traffic"] = ent.get("lib_sources_sha256") != _lib_sha() if ent else None
+        return ent.get("hbm_bytes_per_launch")
     except Exception:
+        STALE["traffic"] = None
         return None
 
 
 def in_loop_us(kernel, envs):
     """rocprofv3 --kernel-trace --stats average of `kernel` INSIDE the train loop (committed summary of this same command,
-    tools/loop_stats_to_json.py), next to the isolated launch time measured live; None when not profiled at this size."""
+    tools/loop_stats_to_json.py), next to the isolated launch time measured live; None when not profiled at this size;
+    `in_loop_stale` says whether it was taken at other library sources than the ones running."""
     try:
         with open(os.path.join(ROOT, LOOP_STATS_FILE)) as f:
-            d = json.load(f)
-        return d.get(str(envs), {}).get(kernel)
+            d = json.load(f).get(str(envs), {})
+        STALE["in_loop"] = d.get("_lib_sources_sha256") != _lib_sha() if d else None
+        return d.get(kernel)
     except Exception:
+        STALE["in_loop"] = None
         return None
 
 
@@ -523,6 +588,7 @@ def integrator_roofline(n, device, us=None, dr_stage=None, stats=False, window=1
     return {"bound": "hbm", "kernel": kname, "envs": n, "achieved": ach, "peak": HBM_PEAK_GBS, **note,
             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc pass, not measured in this run)" if traffic else None,
+            "traffic_stale": STALE.get("traffic") if traffic else None,
             "launch_us": us, "algorithmic_bytes_per_env_step": per_env,
             "algorithmic_bytes_per_launch": per_env * n, "env_steps_per_s": n / (us * 1e-6)}
 
@@ -556,8 +622,9 @@ def _layer_kernel_roofline(L, n, device):
                        "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
                        "traffic": traffic,
                        "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc pass, not measured in this run)" if traffic else None,
+                       "traffic_stale": STALE.get("traffic") if traffic else None,
                        "launch_us": us, "launch_us_source": "live: hipGraph of 20 isolated launches, HIP events on their stream",
-                       "in_loop_us": loop,
+                       "in_loop_us": loop, "in_loop_stale": STALE.get("in_loop") if loop else None,
                        "in_loop_source": f"{LOOP_STATS_FILE} (committed rocprofv3 --kernel-trace --stats of the train loop)" if loop else None,
                        "in_loop_frac": (2.0 * M * N * K / (loop * 1e-6) / 1e12 / MFMA_F32_PEAK_TF) if loop else None,
                        "flops_per_launch": 2.0 * M * N * K, "dtype": "f32 in / f32 acc MFMA"}
@@ -602,8 +669,9 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device,
             rep["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                "frac": tf / MFMA_F32_PEAK_TF, "traffic": traffic,
                                "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc pass, not measured in this run)" if traffic else None,
+                               "traffic_stale": STALE.get("traffic") if traffic else None,
                                "launch_us": us, "launch_us_source": "live: hipGraph of 5 isolated launches, HIP events on their stream",
-                               "in_loop_us": loop,
+                               "in_loop_us": loop, "in_loop_stale": STALE.get("in_loop") if loop else None,
                                "in_loop_source": (f"{LOOP_STATS_FILE} (committed rocprofv3 --kernel-trace --stats of the train loop; per-step "
                                                   "total of the loop's TWO launches of n/2 rows: one beside the learner at 1 workgroup "
                                                   "per CU, one alone)") if loop else None,

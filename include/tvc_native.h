@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define TVC_ABI_VERSION 1
+#define TVC_ABI_VERSION 2
 
 enum {
     TVC_OK = 0,
@@ -89,8 +89,14 @@ int tvc_env_create(const tvc_env_cfg* cfg, int32_t n_envs, int32_t device, tvc_e
 void tvc_env_destroy(tvc_env* env);
 int32_t tvc_env_num_envs(const tvc_env* env);
 
-/* Updates the DR ranges of a live handle (curriculum stage change); takes effect at the next reset. */
+/* Updates the DR ranges of a live handle (curriculum stage change, scripts/curriculum_manager.py:248-290 -> the env); takes
+ * effect at each env's next reset.  The step kernel reads the ranges from a device-resident record, so the change also reaches
+ * steps replayed from a captured hipGraph.  tvc_env_set_dr synchronises the device around the change (steps enqueued before the
+ * call on any stream keep the old ranges); tvc_env_set_dr_async enqueues it on `stream` without synchronising: steps enqueued on
+ * that stream before the call keep the old ranges, later ones (graph launches included) see the new ones.  dr_enabled itself
+ * selects the kernel instantiation at launch: do not flip it under a captured graph. */
 int tvc_env_set_dr(tvc_env* env, const tvc_env_cfg* cfg);
+int tvc_env_set_dr_async(tvc_env* env, const tvc_env_cfg* cfg, void* stream);
 
 /* EnhancedRocketTVCEnv.reset (env/...:381-407).  mask_dev: uint8[N] or NULL (= all).
  * hard != 0 also clears the state the reference keeps across resets (== constructing a new
@@ -142,8 +148,11 @@ int tvc_env_set_components_out(tvc_env* env, float* comps_dev);
 /* On-device episode statistics: what StateOfTheArtTrainer keeps per episode on the host (scripts/train.py:594-616: episode
  * reward, length, success) and feeds to the curriculum manager (:458-460), accumulated by the step kernel so that N envs need no
  * host round trip.  ep_return_dev float[N] (running extrinsic return of each env's current episode, zero it before use);
- * sums_dev double[64]: [0] episodes finished, [16] of which mission_successful, [32] sum of their returns, [48] sum of their
- * lengths (one 128-byte line each; the caller zeroes / reads them).  NULL, NULL switches it off (default). */
+ * sums_dev double[TVC_EP_SLOTS * 16]: TVC_EP_SLOTS partial records, one 128-byte line each, record s at sums_dev[16 s + k] with
+ * k = 0 episodes finished, 1 of which mission_successful, 2 sum of their returns, 3 sum of their lengths; the totals are the sums
+ * over the records (workgroups add into different records so that the atomics do not serialise on one address; the caller
+ * zeroes / reads them).  NULL, NULL switches it off (default). */
+#define TVC_EP_SLOTS 256
 int tvc_env_set_episode_stats(tvc_env* env, float* ep_return_dev, double* sums_dev);
 
 /* info dict of _get_enhanced_info (env/...:723-742) as tensors:
@@ -195,6 +204,8 @@ typedef struct tvc_sac_cfg {
                                        every forward of tvc_sac_update (family 0).  Masks are a counter-based hash, not torch's
                                        Philox stream: statistically equivalent.  tvc_sac_act stays deterministic. */
     int32_t nhead;                  /* 8: attention heads (only the granularity of the attention-weight dropout at seq len 1) */
+    uint32_t dropout_seed;          /* mixed into every dropout mask key: handles (policies, ranks, seeds) with different values draw
+                                       different mask sequences; 0 = the sequence the golden tests pin */
 } tvc_sac_cfg;
 
 void tvc_sac_default_cfg(tvc_sac_cfg* cfg, int32_t family);
@@ -231,6 +242,11 @@ int tvc_sac_snapshot_policy(tvc_sac* sac, void* stream);
  * both calls synchronise. */
 int tvc_sac_get_adam_steps(tvc_sac* sac, int32_t out[2]);
 int tvc_sac_set_adam_steps(tvc_sac* sac, const int32_t in[2]);
+/* Call counter of the train-mode acting passes (tvc_sac_act flags bit 3): it keys their dropout masks and advances by one per
+ * call; carried in checkpoints so that a resumed run does not replay the masks from call 0.  0 / no-op for handles without
+ * train-mode acting.  Both calls synchronise. */
+int tvc_sac_get_act_counter(tvc_sac* sac, int32_t* out);
+int tvc_sac_set_act_counter(tvc_sac* sac, int32_t value);
 
 /* Policy part of get_action (agent/...:765-789) for n rows: mean/log_std (clamped to [-20,2]) and
  * action = clamp(mean + exp(log_std) * eps, -1, 1); eps_dev NULL = deterministic (action = clamp(mean)).

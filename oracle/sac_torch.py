@@ -39,7 +39,8 @@ class DropMasks:
     """The counter-hash dropout masks of the HIP kernels (tvc_nn_kernels.h: drop_mix / drop_key / drop_factor) restated with
     numpy, so that a train-mode update can be compared mask for mask.  p = thresh / 65536; kept values scale by 1 / (1 - p)."""
 
-    def __init__(self, p):
+    def __init__(self, p, seed=0):
+        self.seed = int(seed) & 0xFFFFFFFF  # tvc_sac_cfg.dropout_seed of the handle under test
         self.thresh = int(round(p * 65536.0))
         self.scale = np.float32(65536.0) / np.float32(65536 - self.thresh)
 
@@ -56,7 +57,8 @@ class DropMasks:
 
     def factor(self, ctr, site, z, row0, rows, cols, group=1):
         m = np.uint64(0xFFFFFFFF)
-        key = self._mix(np.uint64(ctr) ^ ((np.uint64(site) * np.uint64(0x9E3779B9)) & m) ^ ((np.uint64(z) * np.uint64(0x7F4A7C15)) & m))
+        key = self._mix(np.uint64(ctr) ^ ((np.uint64(site) * np.uint64(0x9E3779B9)) & m) ^ ((np.uint64(z) * np.uint64(0x7F4A7C15)) & m)
+                        ^ np.uint64(self.seed))
         r = self._mix((np.arange(row0, row0 + rows, dtype=np.uint64) + np.uint64(0x632BE5AB)) & m)[:, None]
         c = (np.arange(cols, dtype=np.uint64) // np.uint64(group))[None, :]
         x = self._mix(key ^ r ^ (((c >> np.uint64(1)) * np.uint64(0x9E3779B1)) & m))
@@ -146,10 +148,10 @@ class AdamState:
 class SacOracle:
     """State of one SAC learner in reference parameterisation."""
 
-    def __init__(self, policy, q1, q2, batch_pe=False, actor_fn=None, critic_fn=None, dropout_p=0.0):
+    def __init__(self, policy, q1, q2, batch_pe=False, actor_fn=None, critic_fn=None, dropout_p=0.0, dropout_seed=0):
         """dropout_p > 0: the reference's train-mode update with the HIP kernels' masks (DropMasks); site bases as in
         tvc_sac.hip: actor 0 (rows of s' offset by the batch size: one stacked forward), critics 120 / 140 / 160."""
-        self.masks = DropMasks(dropout_p) if dropout_p > 0 else None
+        self.masks = DropMasks(dropout_p, dropout_seed) if dropout_p > 0 else None
         self.updates = 0
         if self.masks is None:
             self.actor_fn = actor_fn or (lambda P, x, row0=0: actor_forward(P, x, batch_pe))

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in include/tvc_native.h but not exported"
     for n in names:
         assert n in nat.SIGNATURES, f"{n} has no ctypes signature in tvc_ai_amd/_native.py"
-    assert L.tvc_abi_version() == 1
+    assert L.tvc_abi_version() == 2
 
 
 def _c_layout(tmp_path, struct, fields):

@@ -204,7 +204,8 @@ def test_auto_reset_random_actions_with_contact():
     worst, alive = run_parity(env, vec, acts, st_tol=5e-4, rew_tol=5e-3, forks_ok=True)
     print("auto-reset+contact worst:", worst, "alive", alive.sum(), "/", n)
     parity_log.record("auto_reset_random_actions_with_contact", envs=n, alive=int(alive.sum()), **worst)
-    assert alive.sum() > 0.6 * n and worst["forks"] < 0.2 * n and worst["med"] < 5e-5
+    # bars at what was measured (8.4 % forks, 91.6 % alive: fp32 and fp64 runs of the same stick-slip contact model), VERDICT r2 1c
+    assert alive.sum() > 0.85 * n and worst["forks"] < 0.12 * n and worst["med"] < 5e-5
     epi = env.export_state()["aux"].cpu().numpy()[:, 7]
     assert epi.max() >= 1  # episodes did end and restart
     env.close()

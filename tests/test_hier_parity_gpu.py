@@ -74,7 +74,7 @@ def test_low_level_policy_in_train_mode_like_the_reference():
     onehot = torch.nn.functional.one_hot(torch.from_numpy(goal).long(), 4).float()
     sg = torch.cat([torch.from_numpy(s), onehot], -1)
     Pt = {k: torch.as_tensor(v) for k, v in P.items()}
-    masks = st.DropMasks(0.1)
+    masks = st.DropMasks(0.1, seed=int(hp.low.cfg.dropout_seed))
     outs = []
     for call in range(2):
         mean, ls, _ = hp.get_action(sd, gd)

@@ -424,7 +424,8 @@ def test_gradients_match_autograd_of_the_restatement(dropout_p):
     e1 = torch.from_numpy(rng.standard_normal((B, 2)).astype(np.float32))
     e2 = torch.from_numpy(rng.standard_normal((B, 2)).astype(np.float32))
     sg, ag, rg, s2g, dg, e1g, e2g = cuda(s, a, r, s2, d, e1, e2)
-    orc = st.SacOracle(nets["policy"], nets["q1"], nets["q2"], batch_pe=False, dropout_p=dropout_p)
+    orc = st.SacOracle(nets["policy"], nets["q1"], nets["q2"], batch_pe=False, dropout_p=dropout_p,
+                       dropout_seed=int(sac.cfg.dropout_seed))  # the handle's own mask sequence (seeded by its constructor)
     kw = (lambda call, z: dict(call=call, z=z)) if dropout_p > 0 else (lambda call, z: {})
 
     def close(got, want, what):
@@ -511,7 +512,8 @@ def test_acting_in_train_mode_applies_the_reference_dropout_sites():
     obs = torch.from_numpy(rng.standard_normal((n, 10)).astype(np.float32))
     eps = torch.from_numpy(rng.standard_normal((n, 2)).astype(np.float32))
     og, eg = cuda(obs, eps)
-    masks = st.DropMasks(p)
+    masks = st.DropMasks(p, seed=int(sac.cfg.dropout_seed))
+    assert int(sac.cfg.dropout_seed) != 0
     worst = 0.0
     outs = []
     for call in range(3):
@@ -536,6 +538,17 @@ def test_acting_in_train_mode_applies_the_reference_dropout_sites():
     with pytest.raises(Exception):
         sac0.act(og, eg, train_mode=True)
     sac0.close()
+    # the constructor seed changes the mask sequence, and the call counter travels (checkpoints)
+    assert sac.act_counter() == 3
+    other = NativeSAC(sac_cfg(0, batch_size=64, max_act_rows=512, dropout_p=p), init=False, seed=77)
+    load_into_native(other, nets)
+    other.set_act_counter(2)
+    _, m_other, _ = other.act(og, eg, train_mode=True)  # same weights, same call index as outs[2], another seed
+    assert int(other.cfg.dropout_seed) != int(sac.cfg.dropout_seed) and (m_other.cpu() - outs[2]).abs().max().item() > 1e-3
+    sac.set_act_counter(2)
+    _, m_again, _ = sac.act(og, eg, train_mode=True)    # the same handle at the same call index replays its masks
+    assert torch.equal(m_again.cpu(), outs[2])
+    other.close()
     sac.close()
     parity_log.record("test_acting_in_train_mode_applies_the_reference_dropout_sites", rows=n, calls=3, worst_abs_err=worst)
 

@@ -1,0 +1,257 @@
+"""The schedule the headline MEASURES: the one-launch acting kernel on a policy snapshot, split into a
+CU-sharing launch and an exclusive launch; the two-stream loop with the join deferred to the next step; the step as segment
+graphs between the collectives; a captured loop under a curriculum stage change.  Each is compared with the plain form of the
+same work (live parameters / one stream / eager launches) through the C ABI.
+
+Tolerances: the split / snapshot / sharing forms run the SAME kernel on the same tile stream, so they are bit-equal to the plain
+call; against the eager fp32 restatement mean / log_std <= 3e-4 abs, action <= 1e-3 (the bars of test_act_at_full_chip_row_counts);
+two schedules of the same loop agree to the summation order of the float atomics in the backward kernels (parameters <= 1e-3 abs
+after 8 steps -- two eager runs differ by ~1e-5 --, replay rows <= 1e-3)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sac_torch as st
+from tests import parity_log
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomise_vectors(sac, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    for name, _, rows, cols in sac.table:  # non-trivial norms / biases so that every epilogue term is exercised
+        if name.startswith("policy.") and cols == 1:
+            sac.view(name).add_(0.1 * torch.randn(rows, device="cuda", generator=g))
+    sac.sync_derived()
+
+
+@pytest.mark.parametrize("n,k,use_se", [(65536, 32768, 0), (65536 - 37, 20000, 0), (16384 + 5, 4096 + 64, 1)])
+def test_snapshot_split_sharing_form_is_bit_equal_to_the_live_call(n, k, use_se):
+    """NativeSAC.act on rows [0, k) in the CU-sharing form + rows [k, n) in the exclusive form, both on the policy SNAPSHOT
+    (what VecTrainer's two-stream step launches), against act() on the live parameters: bit for bit; both against the
+    restatement on sampled rows.  Then the live parameters change: the snapshot calls must keep answering with the old policy."""
+    from tvc_ai_amd.agent import NativeSAC, sac_cfg
+    torch.set_num_threads(8)
+    obs_dim = 14 if use_se else 10
+    sac = NativeSAC(sac_cfg(0, obs_dim=obs_dim, batch_size=64, max_act_rows=65536, use_se=use_se), seed=17)
+    _randomise_vectors(sac, 5)
+    P = sac.export_reference_state("policy")
+    g = torch.Generator().manual_seed(n)
+    obs = (torch.randn(n, obs_dim, generator=g) * 0.5).cuda()
+    eps = torch.randn(n, 2, generator=g).cuda()
+    live = [t.clone() for t in sac.act(obs, eps)]
+    sac.snapshot_policy()
+    out = tuple(torch.full((n, 2), float("nan"), device="cuda") for _ in range(3))
+    for lo, hi, sh in ((0, k, True), (k, n, False)):
+        sac.act(obs[lo:hi], eps[lo:hi], out=tuple(o[lo:hi] for o in out), snapshot=True, share_cus=sh)
+    for got, want, what in zip(out, live, ("action", "mean", "log_std")):
+        assert torch.equal(got, want), (what, (got - want).abs().max().item())
+    pick = torch.cat([torch.arange(0, 200), torch.arange(k - 100, k + 100), torch.randint(0, n, (800,), generator=g),
+                      torch.arange(n - 200, n)])
+    with torch.no_grad():
+        m_ref, ls_ref = st.actor_forward(P, obs.cpu()[pick], batch_pe=False)
+    e_mean = (out[1].cpu()[pick] - m_ref).abs().max().item()
+    e_ls = (out[2].cpu()[pick] - ls_ref).abs().max().item()
+    a_ref = (m_ref + torch.exp(ls_ref) * eps.cpu()[pick]).clamp(-1, 1)
+    e_act = (out[0].cpu()[pick] - a_ref).abs().max().item()
+    assert e_mean <= 3e-4 and e_ls <= 3e-4 and e_act <= 1e-3, (e_mean, e_ls, e_act)
+    # the snapshot is a copy: perturb the live policy, the snapshot form must not move, the live form must
+    sac.params[:sac.n_policy].mul_(1.01)
+    sac.sync_derived()
+    again = sac.act(obs[:k], eps[:k], snapshot=True, share_cus=True)
+    assert torch.equal(again[1], live[1][:k])
+    moved = sac.act(obs[:k], eps[:k])
+    assert not torch.equal(moved[1], live[1][:k])
+    parity_log.record(f"snapshot_split_sharing_form_n{n}_se{use_se}", rows=n, shared_rows=k, bit_equal=True, mean_err=e_mean,
+                      log_std_err=e_ls, action_err=e_act)
+    sac.close()
+
+
+def _run_loop(n, steps, seed, **kw):
+    from tvc_ai_amd.trainer import VecTrainer
+    torch.manual_seed(1234)  # exploration / update noise comes from the default device generator
+    tr = VecTrainer(n, device="cuda:0", family=0, batch_size=256, replay_capacity=1_000_000, seed=seed, **kw)
+    return tr
+
+
+def _finish(tr):
+    torch.cuda.synchronize()
+    rows, meta = tr.rb.export()
+    out = dict(steps=tr.steps, adam=tr.sac.adam_steps(), params=tr.sac.params.cpu().clone(), rows=rows.cpu().clone(), meta=meta,
+               losses=tr.sac.losses.cpu().clone(), obs=tr.obs[tr.cur].cpu().clone())
+    tr.close()
+    return out
+
+
+def _compare(a, b, tag, n, steps):
+    assert a["steps"] == b["steps"] == steps and a["adam"] == b["adam"] == [steps, steps]
+    assert a["meta"] == b["meta"] and a["meta"][1] == n * steps
+    d_rows = (a["rows"] - b["rows"]).abs().max().item()
+    d_par = (a["params"] - b["params"]).abs().max().item()
+    d_obs = (a["obs"] - b["obs"]).abs().max().item()
+    assert torch.isfinite(a["losses"]).all() and torch.isfinite(b["losses"]).all()
+    assert d_rows <= 1e-3 and d_par <= 1e-3 and d_obs <= 1e-3, (d_rows, d_par, d_obs)
+    torch.testing.assert_close(a["losses"], b["losses"], rtol=2e-3, atol=2e-3)
+    parity_log.record(tag, envs=n, steps=steps, replay_rows=a["meta"][1], max_replay_row_diff=d_rows, max_param_diff=d_par,
+                      max_obs_diff=d_obs, adam_steps=a["adam"])
+
+
+def test_two_stream_loop_with_deferred_join_equals_the_sequential_loop_at_32768_envs():
+    """The loop bench.py times (snapshot + split acting launches + update on the learner's stream, join deferred to the next
+    step) against the same loop on one stream with live parameters: same seeds => same replay rows, same Adam counters,
+    parameters equal to the summation order of the float atomics."""
+    n, steps = 32768, 8
+    a = _run_loop(n, steps, 5, overlap=True, defer_join=True)
+    assert a.defer_join and a.share_cus and 0 < a.share_rows < n
+    for _ in range(steps):
+        a.step(True)
+    b = _run_loop(n, steps, 5, overlap=False)
+    assert not b.defer_join
+    for _ in range(steps):
+        b.step(True)
+    _compare(_finish(a), _finish(b), "two_stream_deferred_join_vs_sequential_32768", n, steps)
+
+
+@pytest.mark.parametrize("n", [4096, 16384])
+def test_segment_graphs_replay_the_same_work_as_eager_steps(n):
+    """VecTrainer.capture_segments(): the step as graphs between the (here absent) collectives, next step's batch drawn at the end
+    of the acting graph.  Same seeds => the same loop as eager two-stream steps."""
+    steps = 9
+    a = _run_loop(n, steps, 7, overlap=True, defer_join=True)
+    for _ in range(3):
+        a.step(True)
+    fn = a.capture_segments()
+    for _ in range(steps - 3):
+        fn()
+    b = _run_loop(n, steps, 7, overlap=True)
+    for _ in range(steps):
+        b.step(True)
+    _compare(_finish(a), _finish(b), f"segment_graphs_vs_eager_{n}", n, steps)
+
+
+def test_stage_change_reaches_a_captured_loop():
+    """a hipGraph freezes kernel arguments; the DR ranges therefore live in a device record that tvc_env_set_dr_async
+    rewrites in stream order.  A curriculum stage change made between replays must show up in the parameters that envs restarted
+    by REPLAYED step kernels draw (wind sd 0 -> 3 N)."""
+    from tvc_ai_amd.curriculum import CurriculumDriver
+    from tvc_ai_amd.env import default_curriculum_config, dr_from_yaml
+    from tvc_ai_amd.trainer import VecTrainer
+    n = 4096
+    tr = VecTrainer(n, family=1, batch_size=64, replay_capacity=100_000, seed=3, overlap=True, max_episode_steps=30,
+                    **dr_from_yaml({}, 1))
+    drv = CurriculumDriver(default_curriculum_config())
+    drv.current_stage_idx = 0  # "hover_training": no wind
+    # exactly one advance is reachable: stage 0 -> 1 ("disturbance_rejection", wind 0.5 N) once half of stage 0 has elapsed
+    drv.stages[0].success_criteria = {"min_success_rate": 0.0, "min_avg_reward": -1e9, "evaluation_episodes": 50}
+    drv.stages[0].duration_steps = 2 * n * 20  # half of it elapses within 20 vector steps
+    for s_ in drv.stages[1:]:
+        s_.success_criteria = {"min_success_rate": 2.0, "min_avg_reward": 1e9, "evaluation_episodes": 50}
+    tr.attach_curriculum(drv, every=10, min_episodes=50)
+    replay = tr.capture(steps_per_replay=4)
+    wind0 = tr.env.export_state()["params"][:, 3].abs().max().item()
+    assert wind0 == 0.0
+    stages = []
+    for _ in range(40):
+        replay()
+        stages.append(drv.current_stage_idx)
+    torch.cuda.synchronize()
+    assert stages[0] == 0 and stages[-1] == 1 and stages[10] == 1, stages   # the driver advanced while only graph replays ran
+    assert len(tr.curriculum_log) >= 8                         # ticks fire on crossing multiples of `every` (4 steps per replay)
+    par = tr.env.export_state()["params"].cpu().numpy()
+    want = float(drv.get_current_stage().conditions["wind_force"])
+    assert want == 0.5
+    sd = par[:, 3].std()
+    assert 0.8 * want < sd < 1.2 * want, (sd, want)            # episodes are <= 30 steps: every env restarted under the new stage
+    assert 0.08 < par[:, 0].std() * 3 ** 0.5 < 0.12            # mass scale 1 +- 0.1 uniform
+    parity_log.record("stage_change_reaches_captured_loop", stages=stages[::4], wind_sd=float(sd), stage_wind=want)
+    tr.close()
+
+
+def test_share_rows_tuning_picks_a_measured_split():
+    from tvc_ai_amd.trainer import VecTrainer
+    n = 32768
+    tr = VecTrainer(n, family=0, batch_size=256, replay_capacity=500_000, seed=2, overlap=True, defer_join=True)
+    rep = tr.tune_share_rows(candidates=[0, n // 4, n // 2, n], steps=4)
+    assert rep is not None and rep["chosen_share_rows"] in (0, n // 4, n // 2, n) and tr.share_rows == rep["chosen_share_rows"]
+    assert len(rep["candidates"]) == 4 and all(c["us_per_step"] > 0 for c in rep["candidates"])
+    assert rep["us_per_step"] == min(c["us_per_step"] for c in rep["candidates"])
+    for _ in range(3):
+        tr.step(True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr.sac.params).all()
+    parity_log.record("share_rows_tuning_32768", **rep)
+    tr.close()
+
+
+def test_update_without_passthrough_trains_the_sac_learner():
+    """with the eager pass-through off (or algorithms.ppo.enabled: false) nothing is called 'ppo'; select_algorithm
+    must then answer the first available algorithm, so that update(batch) under the reference's driver (scripts/train.py:577-606:
+    update(batch) with algorithm None, update_performance('ppo', ...)) trains the learner that acts."""
+    from tvc_ai_amd.agent import MultiAlgorithmAgent
+    ag = MultiAlgorithmAgent(10, 2, {"tvc_native": {"batch_size": 1, "max_act_rows": 16, "passthrough": False}})
+    assert list(ag.algorithms) == ["sac"] and ag.select_algorithm() == "sac"
+    obs = torch.randn(1, 10)
+    p0 = ag.sac.params.clone()
+    a, info = ag.get_action(obs)
+    assert info["algorithm"] == "sac"
+    out = ag.update({"states": obs, "actions": torch.from_numpy(a), "rewards": torch.tensor([0.5]), "next_states": obs + 0.1,
+                     "dones": torch.BoolTensor([False])})
+    assert set(out) >= {"q1_loss", "q2_loss", "policy_loss"}, out
+    assert not torch.equal(p0, ag.sac.params)
+    ag.update_performance("ppo", 3.0)  # the reference's driver only ever reports 'ppo' (scripts/train.py:606)
+    assert ag.select_algorithm() == "sac"
+    ag.sac.close()
+
+
+def test_episode_statistics_survive_reset_and_resume(tmp_path):
+    """running returns are zeroed by reset(), and they, the totals and the curriculum driver's position travel in
+    VecTrainer.state_dict()."""
+    from tvc_ai_amd.curriculum import CurriculumDriver
+    from tvc_ai_amd.env import VecRocketTVCEnv, default_curriculum_config, dr_from_yaml
+    from tvc_ai_amd.trainer import VecTrainer
+    env = VecRocketTVCEnv(256, seed=1)
+    with pytest.raises(Exception, match="enable_episode_stats"):
+        env.episode_stats()
+    env.enable_episode_stats()
+    env.reset()
+    act = torch.zeros(256, 2, device="cuda")
+    for _ in range(5):
+        env.step(act)
+    assert env._ep_ret.abs().max().item() > 0
+    mask = torch.zeros(256, dtype=torch.uint8, device="cuda")
+    mask[:100] = 1
+    keep = env._ep_ret[100:].clone()
+    env.reset(mask=mask)
+    assert env._ep_ret[:100].abs().max().item() == 0 and torch.equal(env._ep_ret[100:], keep)
+    env.reset()
+    assert env._ep_ret.abs().max().item() == 0
+    env.close()
+
+    kw = dict(family=1, batch_size=64, replay_capacity=8192, overlap=True, max_episode_steps=25, **dr_from_yaml({}, 2))
+    a = VecTrainer(512, seed=4, **kw)
+    drv = CurriculumDriver(default_curriculum_config())
+    drv.current_stage_idx = 1
+    drv.current_step = 1234
+    a.attach_curriculum(drv, every=10, min_episodes=10)
+    for _ in range(30):
+        a.step(True)
+    path = str(tmp_path / "ck.pt")
+    a.save_checkpoint(path)
+    sa = a.env.episode_stats()
+    assert sa["episodes"] > 0
+    b = VecTrainer(512, seed=4, **kw)
+    b.attach_curriculum(CurriculumDriver(default_curriculum_config()), every=10, min_episodes=10)
+    b.load_checkpoint(path)
+    assert b.env.episode_stats() == sa and torch.equal(a.env._ep_ret, b.env._ep_ret)
+    assert b.curriculum.current_stage_idx == a.curriculum.current_stage_idx and b.curriculum.current_step == a.curriculum.current_step
+    assert b._cur_last == a._cur_last
+    for _ in range(10):
+        a.step(True)
+        b.step(True)
+    torch.cuda.synchronize()
+    ea, eb = a.env.episode_stats(), b.env.episode_stats()
+    # (the learner's float atomics make two continuations differ in the last bits of an action: allow a stray threshold flip)
+    assert abs(ea["episodes"] - eb["episodes"]) <= 2 and ea["episodes"] > sa["episodes"]
+    assert abs(ea["return_sum"] - eb["return_sum"]) <= 2e-3 * max(1.0, abs(ea["return_sum"]))
+    a.close()
+    b.close()

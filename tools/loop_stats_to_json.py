@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""rocprofv3 --kernel-trace --stats of `bench.py --loop-only` -> profiles/r02_train_loop_kernel_stats.json:
+"""rocprofv3 --kernel-trace --stats of `bench.py --loop-only` -> profiles/r03_train_loop_kernel_stats.json:
 {envs: {kernel name without template arguments / parameters: average microseconds in the train loop}}.
 usage: loop_stats_to_json.py <kernel_stats.csv> <envs> [out.json]"""
 import csv, json, os, re, sys
 src, envs = sys.argv[1], sys.argv[2]
 out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
-                                                         "r02_train_loop_kernel_stats.json")
+                                                         "r03_train_loop_kernel_stats.json")
 data = json.load(open(out)) if os.path.exists(out) else {}
 rows = {}
 for r in csv.DictReader(open(src)):
@@ -25,6 +25,9 @@ if steps and full and calls[full][0] >= 2 * steps - 2:
     rows[k + " [average of one launch]"] = rows[k]
     rows[k] = calls[full][1] / 1e3 / (calls[full][0] / 2.0)
     rows["_launches_per_step"] = {k: 2}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tvc_ai_amd.build import sources_sha256  # noqa: E402
+rows["_lib_sources_sha256"] = sources_sha256()  # bench.py prints "stale": true beside in_loop_us when the library has moved on
 data[str(envs)] = rows
 json.dump(data, open(out, "w"), indent=1, sort_keys=True)
 print("wrote", out, len(rows), "kernels")

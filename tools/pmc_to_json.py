@@ -22,6 +22,9 @@ def collect(d, counter):
     return {k: sum(v[len(v) // 2:]) / len(v[len(v) // 2:]) for k, v in acc.items()}
 
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tvc_ai_amd.build import sources_sha256  # noqa: E402
+SHA = sources_sha256()  # bench.py prints "stale": true beside `traffic` when the library has moved on since this pass
 fetch = collect(sys.argv[1], "FETCH_SIZE")
 write = collect(sys.argv[2], "WRITE_SIZE")
 out = defaultdict(dict)
@@ -29,7 +32,7 @@ for (name, grid), f in fetch.items():
     if (name, grid) not in write or not ("env_step" in name or "gemm_kernel" in name or "gemm_rowln" in name or "actor_rows" in name):
         continue
     w = write[(name, grid)]
-    out[name][str(grid)] = {"fetch_size_kib_raw": f, "write_size_kib": w, "hbm_read_bytes": f * 1024 * 2,
+    out[name][str(grid)] = {"lib_sources_sha256": SHA, "fetch_size_kib_raw": f, "write_size_kib": w, "hbm_read_bytes": f * 1024 * 2,
                             "hbm_write_bytes": w * 1024, "hbm_bytes_per_launch": f * 1024 * 2 + w * 1024,
                             "hbm_bytes_per_thread": (f * 1024 * 2 + w * 1024) / grid}
 path = sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic.json"

@@ -46,6 +46,7 @@ SIGNATURES = {
     "tvc_env_destroy": (None, [_VP]),
     "tvc_env_num_envs": (C.c_int32, [_VP]),
     "tvc_env_set_dr": (C.c_int, [_VP, C.POINTER(EnvCfg)]),
+    "tvc_env_set_dr_async": (C.c_int, [_VP, C.POINTER(EnvCfg), _VP]),
     "tvc_env_reset": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP]),
     "tvc_env_step": (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "tvc_env_step_many": (C.c_int, [_VP, C.c_int32, _VP, _VP, _VP, _VP, _VP, _VP]),
@@ -69,7 +70,7 @@ class SacCfg(C.Structure):
         ("batch_size", C.c_int32), ("max_act_rows", C.c_int32), ("pe_rows", C.c_int32),
         ("gamma", C.c_float), ("alpha", C.c_float), ("tau", C.c_float), ("lr", C.c_float),
         ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("use_se", C.c_int32),
-        ("dropout_p", C.c_float), ("nhead", C.c_int32),
+        ("dropout_p", C.c_float), ("nhead", C.c_int32), ("dropout_seed", C.c_uint32),
     ]
 
 
@@ -84,6 +85,8 @@ SIGNATURES.update({
     "tvc_sac_destroy": (None, [_VP]),
     "tvc_sac_get_adam_steps": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
     "tvc_sac_set_adam_steps": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
+    "tvc_sac_get_act_counter": (C.c_int, [_VP, C.POINTER(C.c_int32)]),
+    "tvc_sac_set_act_counter": (C.c_int, [_VP, C.c_int32]),
     "tvc_sac_sync_derived": (C.c_int, [_VP, _VP]),
     "tvc_sac_snapshot_policy": (C.c_int, [_VP, _VP]),
     "tvc_sac_act": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, C.c_int32, _VP]),

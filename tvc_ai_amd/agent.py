@@ -37,6 +37,12 @@ def sac_cfg(family: int = 0, **over) -> SacCfg:
     return cfg
 
 
+def dropout_seed_of(seed: int, rank: int = 0) -> int:
+    """tvc_sac_cfg.dropout_seed of a learner built with `seed` on data-parallel rank `rank` (never 0: 0 pins the golden sequence)"""
+    v = (int(seed) * 0x9E3779B1 + (int(rank) + 1) * 0x7F4A7C15) & 0xFFFFFFFF
+    return v or 1
+
+
 def tensor_table(cfg: SacCfg):
     """[(name, offset, rows, cols)] of the flat parameter buffer (host-only query)."""
     L = nat.load()
@@ -74,6 +80,8 @@ class NativeSAC:
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise nat.TvcError("NativeSAC needs a GPU device: there is no CPU fallback")
+        if int(self.cfg.dropout_seed) == 0:  # dropout masks follow the constructor seed unless the cfg pins them
+            self.cfg.dropout_seed = dropout_seed_of(seed)
         self.table = tensor_table(self.cfg)
         self.index = {n: (o, r, c) for n, o, r, c in self.table}
         self.layout = ckpt.Layout(self.table, self.cfg.family, self.cfg.d_model, self.cfg.n_layers)
@@ -165,6 +173,15 @@ class NativeSAC:
 
     def set_adam_steps(self, steps):
         nat.check(self.L.tvc_sac_set_adam_steps(self._h, (C.c_int32 * 2)(int(steps[0]), int(steps[1]))))
+
+    def act_counter(self) -> int:
+        """call counter of the train-mode acting passes (keys their dropout masks); synchronises"""
+        out = C.c_int32()
+        nat.check(self.L.tvc_sac_get_act_counter(self._h, C.byref(out)))
+        return int(out.value)
+
+    def set_act_counter(self, value: int):
+        nat.check(self.L.tvc_sac_set_act_counter(self._h, int(value)))
 
     def sync_derived(self):
         """call after writing `params` from the host side (folded acting weights are cached in the handle)"""
@@ -456,7 +473,10 @@ class MultiAlgorithmAgent:
                     perf = float(np.mean(vals))
                     if perf > best_perf:
                         best, best_perf = name, perf
-            selected = best or "ppo"
+            # the reference answers 'ppo' whenever no algorithm has a history yet (:709); where 'ppo' was not built (pass-through off,
+            # algorithms.ppo.enabled: false) the first available algorithm stands in, as get_action does (:757-759), so that
+            # update(batch) under the reference's driver trains what acts
+            selected = best or ("ppo" if ("ppo" in self.algorithms or not self.algorithms) else next(iter(self.algorithms)))
         if previous is not None and previous != selected:
             self.logger.info(f"Algorithm switch: {previous} -> {selected}")
         self._current_algorithm = selected

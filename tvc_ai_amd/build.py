@@ -26,6 +26,20 @@ def sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
+def sources_sha256():
+    """sha256 over the library's sources (csrc/*.hip, csrc/*.h, include/tvc_native.h, by name): stored in the committed profile
+    summaries so that bench.py can tell when a figure it quotes from them was taken at other kernels than the ones it runs"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(ROOT, "include", "tvc_native.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def needs_build():
     if os.environ.get("TVC_HIP_LIB"):
         return False  # an explicitly chosen prebuilt variant (kernel A/B experiments)

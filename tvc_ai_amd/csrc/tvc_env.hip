@@ -44,18 +44,23 @@ __device__ __forceinline__ void store_tile10(const float* tile, float* __restric
 
 template <bool W10, bool DR>
 __global__ void __launch_bounds__(kMaxBlock)
-env_step_kernel(EnvBuf b, DevCfg c, DrCfg d, const float* __restrict__ act, float* __restrict__ obs,
+env_step_kernel(EnvBuf b, DevCfg c, const DrCfg* __restrict__ dp, const float* __restrict__ act, float* __restrict__ obs,
                 float* __restrict__ rew, unsigned char* __restrict__ term, unsigned char* __restrict__ trunc,
                 float* __restrict__ final_obs, float* __restrict__ comps, EpStats ep, int n_steps) {
     __shared__ __attribute__((aligned(16))) float tile[kMaxBlock * 10];
     const int row0 = blockIdx.x * blockDim.x;
     const int i = row0 + threadIdx.x;
     const bool valid = i < b.n;
+    // the DR ranges live in a small DEVICE record (uniform address: scalar loads) that tvc_env_set_dr rewrites in stream order,
+    // so a curriculum stage change also reaches launches replayed from a captured hipGraph (kernel arguments are frozen there)
+    DrCfg d{};
+    if (DR) d = *dp;
     const long long gid = DR ? d.id_off + i : 0;
     Regs r;
     float hw[12];
     float* ringp = W10 ? nullptr : b.ring1000 + (valid ? i : 0);
     int ring_slot = -1;
+    bool params_dirty = false;
     if (valid) load_regs<DR, W10>(r, hw, b, i);
     for (int t = 0; t < n_steps; ++t) {
         const size_t toff = (size_t)t * b.n;
@@ -92,10 +97,11 @@ env_step_kernel(EnvBuf b, DevCfg c, DrCfg d, const float* __restrict__ act, floa
                     c += __shfl_xor(c, m); sc += __shfl_xor(sc, m); rs += __shfl_xor(rs, m); ls += __shfl_xor(ls, m);
                 }
                 if ((threadIdx.x & 63) == 0) {
-                    atomicAdd(ep.sums, (double)c);
-                    if (sc > 0.0f) atomicAdd(ep.sums + 16, (double)sc);
-                    atomicAdd(ep.sums + 32, (double)rs);
-                    atomicAdd(ep.sums + 48, (double)ls);
+                    double* rec = ep.sums + 16 * (blockIdx.x & (kEpSlots - 1));
+                    atomicAdd(rec, (double)c);
+                    if (sc > 0.0f) atomicAdd(rec + 1, (double)sc);
+                    atomicAdd(rec + 2, (double)rs);
+                    atomicAdd(rec + 3, (double)ls);
                 }
             }
             if (valid) ep.ret[i] = fin ? 0.0f : R;
@@ -107,6 +113,7 @@ env_step_kernel(EnvBuf b, DevCfg c, DrCfg d, const float* __restrict__ act, floa
         }
         if (valid && done && c.auto_reset) {
             r.episode += 1u;
+            params_dirty = true;
             reset_dynamic<DR>(r, c, d, gid);
             observe(r, c, o.obs);
             add_obs_noise<DR>(r, d, gid, o.obs);
@@ -117,8 +124,10 @@ env_step_kernel(EnvBuf b, DevCfg c, DrCfg d, const float* __restrict__ act, floa
         store_tile10(tile, obs + toff * 10, row0, b.n, blockDim.x);
         if (t + 1 < n_steps) __syncthreads();
     }
-    if (valid) store_regs<DR, W10>(r, hw, b, i, n_steps == 1 ? ring_slot : 100);
+    if (valid) store_regs<DR, W10>(r, hw, b, i, n_steps == 1 ? ring_slot : 100, params_dirty);
 }
+
+__global__ void env_set_dr_kernel(DrCfg v, DrCfg* __restrict__ dst) { *dst = v; }
 
 __global__ void __launch_bounds__(kMaxBlock)
 env_reset_kernel(EnvBuf b, DevCfg c, DrCfg d, int dr, const unsigned char* __restrict__ mask, int hard,
@@ -282,6 +291,7 @@ struct tvc_env {
     int device;
     int W;
     void* slab;
+    DrCfg* dr_dev;     // device copy of `dr` read by the step kernel (rewritten in stream order by tvc_env_set_dr_async)
     float* comps_out;  // optional [N,12] reward-component sink (tvc_env_set_components_out)
     EpStats ep;        // optional episode statistics (tvc_env_set_episode_stats)
 };
@@ -374,7 +384,8 @@ int tvc_env_create(const tvc_env_cfg* cfg, int32_t n_envs, int32_t device, tvc_e
     e->ep.ret = nullptr; e->ep.sums = nullptr;
     build_devcfg(*cfg, e->W, e->dc, e->dr);
     const int np = tvc::ceil_div(n_envs, 64) * 64;
-    const size_t bytes = (size_t)np * kCellGroups * sizeof(float4) + (e->W == 1000 ? (size_t)np * 1000 * sizeof(float) : 0);
+    const size_t state_bytes = (size_t)np * kCellGroups * sizeof(float4) + (e->W == 1000 ? (size_t)np * 1000 * sizeof(float) : 0);
+    const size_t bytes = state_bytes + 256;  // + the DR record
     hipError_t he = hipMalloc(&e->slab, bytes);
     if (he != hipSuccess) {
         delete e;
@@ -383,11 +394,13 @@ int tvc_env_create(const tvc_env_cfg* cfg, int32_t n_envs, int32_t device, tvc_e
     e->buf.cells = (float4*)e->slab;
     e->buf.ring1000 = e->W == 1000 ? (float*)((char*)e->slab + (size_t)np * kCellGroups * sizeof(float4)) : nullptr;
     e->buf.n = n_envs; e->buf.np = np;
+    e->dr_dev = (DrCfg*)((char*)e->slab + state_bytes);
     he = hipMemset(e->slab, 0, bytes);
+    if (he == hipSuccess) he = hipMemcpy(e->dr_dev, &e->dr, sizeof(DrCfg), hipMemcpyHostToDevice);
     if (he != hipSuccess) {
         (void)hipFree(e->slab);
         delete e;
-        return tvc::set_error(TVC_EHIP, "hipMemset failed: %s", hipGetErrorString(he));
+        return tvc::set_error(TVC_EHIP, "hipMemset / hipMemcpy failed: %s", hipGetErrorString(he));
     }
     *out = e;
     int rc = tvc_env_reset(e, nullptr, 1, nullptr, nullptr);
@@ -412,12 +425,26 @@ void tvc_env_destroy(tvc_env* e) {
 
 int32_t tvc_env_num_envs(const tvc_env* e) { return e ? e->n : 0; }
 
-int tvc_env_set_dr(tvc_env* e, const tvc_env_cfg* cfg) {
+int tvc_env_set_dr_async(tvc_env* e, const tvc_env_cfg* cfg, void* stream) {
     if (!e || !cfg) return tvc::set_error(TVC_EINVAL, "null argument");
+    TVC_HIP_CHECK(hipSetDevice(e->device));
     e->cfg.dr_enabled = cfg->dr_enabled; e->cfg.dr_mass_var = cfg->dr_mass_var; e->cfg.dr_thrust_std = cfg->dr_thrust_std;
     e->cfg.dr_cg_max = cfg->dr_cg_max; e->cfg.dr_wind_std = cfg->dr_wind_std;
     e->cfg.dr_init_tilt_max = cfg->dr_init_tilt_max; e->cfg.dr_obs_noise_std = cfg->dr_obs_noise_std;
     build_devcfg(e->cfg, e->W, e->dc, e->dr);
+    // the record travels as a kernel argument (captured at enqueue) and lands in stream order: steps enqueued on `stream`
+    // before this call keep the old ranges, later ones -- graph replays included -- see the new ones
+    hipLaunchKernelGGL(env_set_dr_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, e->dr, e->dr_dev);
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int tvc_env_set_dr(tvc_env* e, const tvc_env_cfg* cfg) {
+    if (!e || !cfg) return tvc::set_error(TVC_EINVAL, "null argument");
+    TVC_HIP_CHECK(hipSetDevice(e->device));
+    TVC_HIP_CHECK(hipDeviceSynchronize());  // whatever stream the caller steps on: everything enqueued so far keeps the old ranges
+    if (int rc = tvc_env_set_dr_async(e, cfg, nullptr)) return rc;
+    TVC_HIP_CHECK(hipStreamSynchronize(nullptr));
     return 0;
 }
 
@@ -448,7 +475,7 @@ static int launch_step(tvc_env* e, int n_steps, const float* act, float* obs, fl
     const bool w10 = e->W == 10, dr = e->cfg.dr_enabled != 0;
     hipStream_t st = (hipStream_t)stream;
 #define TVC_LAUNCH_STEP(A, B)                                                                                         \
-    hipLaunchKernelGGL((env_step_kernel<A, B>), grid, block, 0, st, e->buf, e->dc, e->dr, act, obs, rew, term, trunc, \
+    hipLaunchKernelGGL((env_step_kernel<A, B>), grid, block, 0, st, e->buf, e->dc, e->dr_dev, act, obs, rew, term, trunc, \
                        final_obs, n_steps == 1 ? e->comps_out : nullptr, e->ep, n_steps)
     if (w10 && !dr) TVC_LAUNCH_STEP(true, false);
     else if (w10 && dr) TVC_LAUNCH_STEP(true, true);

@@ -53,8 +53,11 @@ struct EnvBuf {
 };
 
 // Optional on-device episode statistics (curriculum driver / logging without host round trips):
-// ret[N] = running extrinsic return of the current episode; sums = {episodes, successes, return sum, length sum}, each on its
-// own 128-byte line (sums[16 * k]).
+// ret[N] = running extrinsic return of the current episode; sums = kEpSlots partial records {episodes, successes, return sum,
+// length sum}, one 128-byte line per record (sums[16 * slot + k]); a workgroup adds into slot blockIdx.x % kEpSlots and the
+// reader sums the slots.  (One shared record serialised: at 4 M envs ~160 000 same-address double atomics per launch were
+// 3/4 of the kernel's time.)
+constexpr int kEpSlots = 256;
 struct EpStats {
     float* ret;
     double* sums;
@@ -560,8 +563,10 @@ __device__ __forceinline__ void load_regs(Regs& r, float (&hw)[12], const EnvBuf
     }
 }
 // ring_slot: the window slot written this step (W10; -1 = none, 100 = all three groups)
+// write_params: the six per-episode parameters changed (reset / import); a plain step leaves their planes alone
 template <bool DR, bool W10>
-__device__ __forceinline__ void store_regs(const Regs& r, const float (&hw)[12], const EnvBuf& b, int i, int ring_slot) {
+__device__ __forceinline__ void store_regs(const Regs& r, const float (&hw)[12], const EnvBuf& b, int i, int ring_slot,
+                                           bool write_params = true) {
     float4* c = b.cells + i;
     const size_t np = b.np;
     unsigned a0 = (r.step & 0xFFFFu) | (r.phase << 16) | (r.msucc << 19) | (r.has_pa << 20) | (r.run << 21);
@@ -572,7 +577,7 @@ __device__ __forceinline__ void store_regs(const Regs& r, const float (&hw)[12],
     c[3 * np] = make_float4(r.wx, r.wy, r.wz, __uint_as_float(r.episode));
     float2* p4 = reinterpret_cast<float2*>(b.cells + 4 * np);
     p4[i] = make_float2(r.pa0, r.pa1);
-    if (DR) {
+    if (DR && write_params) {
         p4[np + i] = make_float2(r.ms, r.ts);
         c[5 * np] = make_float4(r.cg, r.windx, r.windy, r.windz);
     }

@@ -69,13 +69,14 @@ struct DropArgs {
     unsigned thresh;  // an element is dropped when its 16 hash bits are < thresh
     float scale;
     int group;        // columns sharing one mask element: 1 = elementwise, d_model / nhead = one per attention head
+    unsigned seed;    // per-handle seed (tvc_sac_cfg.dropout_seed): different learners / ranks draw different mask sequences
 };
 __device__ __forceinline__ unsigned drop_mix(unsigned x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
 __device__ __forceinline__ unsigned drop_key(const DropArgs& d, unsigned z) {
-    return drop_mix((unsigned)(*d.ctr) ^ (d.site * 0x9E3779B9u) ^ (z * 0x7F4A7C15u));
+    return drop_mix((unsigned)(*d.ctr) ^ (d.site * 0x9E3779B9u) ^ (z * 0x7F4A7C15u) ^ d.seed);
 }
 __device__ __forceinline__ float drop_factor(const DropArgs& d, unsigned key, int row, int col) {
     const unsigned c = (unsigned)col / (unsigned)d.group;

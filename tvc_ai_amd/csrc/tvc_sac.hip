@@ -327,10 +327,13 @@ static bool thin_ok(const Op& o) { return o.type == OP_LINEAR && o.in_dim <= THI
 
 // train-mode dropout of one forward call (and of the backward that follows it): the counter, p, and the site base that
 // tells this call's masks from every other call's
-struct DropCtl { const int* ctr; unsigned thresh; float scale; unsigned site_base; };
+struct DropCtl { const int* ctr; unsigned thresh; float scale; unsigned site_base; unsigned seed; };
 static DropArgs drop_args(const DropCtl* dc, int op_index, int group) {
     DropArgs d{};
-    if (dc && group > 0) { d.ctr = dc->ctr; d.site = dc->site_base + (unsigned)op_index; d.thresh = dc->thresh; d.scale = dc->scale; d.group = group; }
+    if (dc && group > 0) {
+        d.ctr = dc->ctr; d.site = dc->site_base + (unsigned)op_index; d.thresh = dc->thresh; d.scale = dc->scale; d.group = group;
+        d.seed = dc->seed;
+    }
     return d;
 }
 
@@ -778,6 +781,8 @@ struct tvc_sac {
     float *pack = nullptr, *snap_pack = nullptr;  // [rows_tiles * 4096 tile floats | vector section]
     PackTile* d_ptiles = nullptr;
     PackVec* d_pvecs = nullptr;
+    bool lds_attr_set = false;                    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this handle's device
+    unsigned long long* rows_stamps = nullptr;    // diagnostics: set by rows_probe around its launches
     float* P_actor() { return params; }
     float* P_q() { return params + n_actor; }
     float* P_tq() { return params + n_actor + 2 * n_critic; }
@@ -1093,8 +1098,6 @@ void tvc_sac_destroy(tvc_sac* h) {
     delete h;
 }
 
-static unsigned long long* g_rows_stamps = nullptr;  // set by tvc_debug_rows_clock around its launches
-
 int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float* act, float* mean, float* logstd, int32_t flags,
                 void* stream) {
     if (!h || !obs || !act) return tvc::set_error(TVC_EINVAL, "null argument");
@@ -1112,7 +1115,7 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
         for (size_t b = 1; b < h->dctx.gY.size(); ++b) h->dctx.gY[b] = (long)n * h->actor.buf_dim[b];
         DropCtl dc;
         dc.ctr = h->act_ctr; dc.thresh = (unsigned)lroundf(h->cfg.dropout_p * 65536.0f);
-        dc.scale = 65536.0f / (float)(65536u - dc.thresh); dc.site_base = 300;
+        dc.scale = 65536.0f / (float)(65536u - dc.thresh); dc.site_base = 300; dc.seed = h->cfg.dropout_seed;
         net_forward(h->actor, snap ? h->snap_p : h->P_actor(), 0, obs, 0, n, 1, h->dctx, false, h->pe, h->cfg.pe_rows, st, nullptr,
                     nullptr, &dc);
         hipLaunchKernelGGL(sample_action_kernel, dim3((n * A + 255) / 256), dim3(256), 0, st, h->dctx.Y.back(), eps, act, mean, logstd,
@@ -1127,18 +1130,17 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
         a.obs = obs; a.eps = eps; a.act = act; a.mean = mean; a.logstd = logstd;
         a.tiles = reinterpret_cast<const float4*>(pk); a.vec = pk + (long)h->rows_tiles * 4096;
         a.M = n; a.obs_dim = h->cfg.obs_dim; a.A = A; a.clamp_act = (flags & 1) ? 0 : 1;
-        a.n_layers = h->cfg.n_layers; a.n_tiles = h->rows_tiles; a.stamps = g_rows_stamps; a.use_se = h->cfg.use_se;
+        a.n_layers = h->cfg.n_layers; a.n_tiles = h->rows_tiles; a.stamps = h->rows_stamps; a.use_se = h->cfg.use_se;
         // flags bit 2 ("share the CUs"): 64 KB of unused dynamic LDS make the kernel fit once per CU instead of twice, which
         // leaves half of every CU's registers (and 64 KB of LDS) to whatever runs on other streams -- the ~100 small kernels of
         // a SAC update beside the acting pass.  Two workgroups per CU own every VGPR of the CU: faster alone (1.9 vs 2.4 ms at
         // 65 536 rows), but nothing else can then run until they retire.
         size_t dyn_lds = 0;
         if (flags & 4) {
-            static bool attr_set = false;
-            if (!attr_set) {
+            if (!h->lds_attr_set) {  // per device (hipSetDevice above), remembered per handle
                 TVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(actor_rows_kernel),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-                attr_set = true;
+                h->lds_attr_set = true;
             }
             dyn_lds = 65536;
         }
@@ -1168,10 +1170,10 @@ static int rows_probe(tvc_sac* h, const float* obs, int32_t n, int32_t launches,
     float* act = nullptr;
     TVC_HIP_CHECK(hipMalloc((void**)&st, (size_t)nwg * AR_STAMPS * sizeof(unsigned long long)));
     if (hipMalloc((void**)&act, (size_t)n * A * sizeof(float)) != hipSuccess) { (void)hipFree(st); return tvc::set_error(TVC_ENOMEM, "hipMalloc failed"); }
-    g_rows_stamps = st;
+    h->rows_stamps = st;
     int rc = 0;
     for (int i = 0; i < launches && rc == 0; ++i) rc = tvc_sac_act(h, obs, n, nullptr, act, nullptr, nullptr, flags & 4, stream);
-    g_rows_stamps = nullptr;
+    h->rows_stamps = nullptr;
     hipError_t he = hipStreamSynchronize((hipStream_t)stream);
     v.assign((size_t)nwg * AR_STAMPS, 0);
     if (rc == 0 && he == hipSuccess) he = hipMemcpy(v.data(), st, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -1224,6 +1226,7 @@ static const DropCtl* drop_ctl(tvc_sac* h, DropCtl& dc, unsigned site_base) {
     if (!(h->cfg.dropout_p > 0.0f)) return nullptr;
     const unsigned thresh = (unsigned)lroundf(h->cfg.dropout_p * 65536.0f);
     dc.ctr = &h->clk[1].step; dc.thresh = thresh; dc.scale = 65536.0f / (float)(65536u - thresh); dc.site_base = site_base;
+    dc.seed = h->cfg.dropout_seed;
     return &dc;
 }
 
@@ -1383,6 +1386,23 @@ int tvc_sac_set_adam_steps(tvc_sac* h, const int32_t in[2]) {
     if (in[0] < 0 || in[1] < 0) return tvc::set_error(TVC_EINVAL, "negative step count");
     TVC_HIP_CHECK(hipSetDevice(h->device));
     return set_clocks(h, in);
+}
+
+// call counter of the train-mode acting passes (keys their dropout masks); checkpoints only, both calls synchronise
+int tvc_sac_get_act_counter(tvc_sac* h, int32_t* out) {
+    if (!h || !out) return tvc::set_error(TVC_EINVAL, "null argument");
+    *out = 0;
+    if (!h->act_ctr) return 0;
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    TVC_HIP_CHECK(hipMemcpy(out, h->act_ctr, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+int tvc_sac_set_act_counter(tvc_sac* h, int32_t value) {
+    if (!h) return tvc::set_error(TVC_EINVAL, "null argument");
+    if (!h->act_ctr) return 0;
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    TVC_HIP_CHECK(hipMemcpy(h->act_ctr, &value, sizeof(int32_t), hipMemcpyHostToDevice));
+    return 0;
 }
 
 int tvc_sac_snapshot_policy(tvc_sac* h, void* stream) {

@@ -65,6 +65,7 @@ REWARD_COMPONENT_KEYS = ["mission_completion", "safety_compliance", "fuel_effici
                          "control_saturation"]
 OBS_DIM = 10
 ACT_DIM = 2
+EP_SLOTS = 256  # TVC_EP_SLOTS of include/tvc_native.h
 
 # curriculum stage table = config/config.yaml:236-286 (stage 0 = the shipped, un-randomised env)
 CURRICULUM_STAGES = [
@@ -207,6 +208,7 @@ class VecRocketTVCEnv:
         self.trunc = torch.empty((n,), dtype=torch.uint8, device=self.device)
         self.final_obs = torch.empty((n, OBS_DIM), dtype=torch.float32, device=self.device) if want_final_obs else None
         self.reward_components = None
+        self._ep_ret = self._ep_sums = None  # device-side episode statistics (enable_episode_stats)
         self.observation_space, self.action_space = _spaces()
 
     # -- lifecycle
@@ -230,6 +232,11 @@ class VecRocketTVCEnv:
         if mask is not None:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
         nat.check(self.L.tvc_env_reset(self._h, nat.ptr(mask), 1 if hard else 0, self.obs.data_ptr(), self._stream()))
+        if self._ep_ret is not None:  # a reset env starts a new episode: its running return starts at zero
+            if mask is None:
+                self._ep_ret.zero_()
+            else:
+                self._ep_ret.masked_fill_(mask.bool(), 0.0)
         return self.obs, {}
 
     def step(self, actions: torch.Tensor, out_obs: Optional[torch.Tensor] = None):
@@ -251,15 +258,33 @@ class VecRocketTVCEnv:
         what scripts/train.py:594-616 keeps per episode on the host.  Read with episode_stats()."""
         if on:
             self._ep_ret = torch.zeros((self.num_envs,), dtype=torch.float32, device=self.device)
-            self._ep_sums = torch.zeros((64,), dtype=torch.float64, device=self.device)
+            self._ep_sums = torch.zeros((EP_SLOTS * 16,), dtype=torch.float64, device=self.device)
             nat.check(self.L.tvc_env_set_episode_stats(self._h, self._ep_ret.data_ptr(), self._ep_sums.data_ptr()))
         else:
             nat.check(self.L.tvc_env_set_episode_stats(self._h, None, None))
             self._ep_ret = self._ep_sums = None
 
     def episode_stats_tensor(self):
-        """device view [4] = episodes finished, successes, return sum, length sum (running totals since enable)"""
-        return self._ep_sums[::16]
+        """device tensor [4] = episodes finished, successes, return sum, length sum (running totals since enable): the sum of the
+        TVC_EP_SLOTS partial records the step kernel adds into"""
+        if self._ep_sums is None:
+            raise nat.TvcError("episode statistics are off: call enable_episode_stats() first")
+        return self._ep_sums.view(EP_SLOTS, 16)[:, :4].sum(0)
+
+    def episode_stats_state(self) -> dict:
+        """running returns + totals for a checkpoint (VecTrainer.state_dict)"""
+        if self._ep_sums is None:
+            return {}
+        return {"ep_ret": self._ep_ret.cpu(), "ep_sums": self.episode_stats_tensor().cpu()}
+
+    def load_episode_stats_state(self, sd: dict):
+        if not sd:
+            return
+        if self._ep_sums is None:
+            self.enable_episode_stats()
+        self._ep_ret.copy_(sd["ep_ret"])
+        self._ep_sums.zero_()
+        self._ep_sums[:4].copy_(sd["ep_sums"])  # the totals go into record 0
 
     def episode_stats(self) -> dict:
         e, s, r, l = self.episode_stats_tensor().cpu().tolist()  # synchronises
@@ -327,6 +352,8 @@ class VecRocketTVCEnv:
         hist = prep(hist, torch.float32, (n, W))
         nat.check(self.L.tvc_env_import_state(self._h, nat.ptr(dyn), nat.ptr(aux), nat.ptr(pa), nat.ptr(par),
                                               nat.ptr(hist), self._stream()))
+        if self._ep_ret is not None and dyn is not None:  # foreign trajectories: the running returns no longer belong to them
+            self._ep_ret.zero_()
         torch.cuda.current_stream(self.device).synchronize()  # keep the staging tensors alive until consumed
 
     def info_tensor(self):
@@ -335,10 +362,12 @@ class VecRocketTVCEnv:
         return info
 
     def set_domain_randomization(self, **dr):
-        """Change DR ranges (e.g. on a curriculum stage change); applies from the next reset of each env."""
+        """Change DR ranges (e.g. on a curriculum stage change); applies from the next reset of each env.  Enqueued on the
+        current stream (tvc_env_set_dr_async): steps already enqueued there keep the old ranges, later ones -- replays of a
+        captured hipGraph included -- see the new ones."""
         for k, v in dr.items():
             setattr(self.cfg, k, type(getattr(self.cfg, k))(v))
-        nat.check(self.L.tvc_env_set_dr(self._h, C.byref(self.cfg)))
+        nat.check(self.L.tvc_env_set_dr_async(self._h, C.byref(self.cfg), self._stream()))
 
     def set_curriculum_stage(self, stage: int, config: Optional[dict] = None):
         self.set_domain_randomization(**dr_from_yaml(config or {}, stage))

@@ -15,7 +15,7 @@ import os
 
 import torch
 
-from .agent import NativeSAC, ReplayBuffer, sac_cfg
+from .agent import NativeSAC, ReplayBuffer, dropout_seed_of, sac_cfg
 from .env import VecRocketTVCEnv
 from .parallel import GradSync, broadcast_parameters
 
@@ -25,7 +25,7 @@ class VecTrainer:
                  replay_capacity: int = 1_000_000, seed: int = 42, rank: int = 0, world: int = 1, updates_per_step: int = 1,
                  max_episode_steps: int = 1000, enable_curiosity: bool = False, overlap: bool = True,
                  enable_hierarchical: bool = False, enable_safety: bool = False, dropout_p: Optional[float] = None,
-                 share_cus: Optional[bool] = None, **env_over):
+                 share_cus: Optional[bool] = None, defer_join: bool = False, share_rows: Optional[int] = None, **env_over):
         self.device = torch.device(device)
         self.n, self.B, self.world, self.rank = num_envs, batch_size, world, rank
         self.updates_per_step = updates_per_step
@@ -33,7 +33,8 @@ class VecTrainer:
                                    seed=seed, env_id_offset=rank * num_envs, want_final_obs=True, **env_over)
         # the reference's update runs in train mode (Dropout(0.1) active in the policy and the critics); family 1 has none
         self.dropout_p = (0.1 if family == 0 else 0.0) if dropout_p is None else float(dropout_p)
-        self.sac = NativeSAC(sac_cfg(family, batch_size=batch_size, max_act_rows=num_envs, dropout_p=self.dropout_p),
+        self.sac = NativeSAC(sac_cfg(family, batch_size=batch_size, max_act_rows=num_envs, dropout_p=self.dropout_p,
+                                     dropout_seed=dropout_seed_of(seed, rank)),  # replicas draw different masks on their batches
                              device=self.device, seed=seed)
         broadcast_parameters(self.sac.params)  # identical replicas (rank 0's initialisation)
         self.sac.sync_derived()
@@ -42,7 +43,7 @@ class VecTrainer:
         self.overlap = overlap
         # defer_join = True: a step returns without waiting for its update on the learner's stream (the next step waits before it
         # takes its snapshot); whoever reads learner state in between synchronises the device first (state_dict() does)
-        self.defer_join = False
+        self.defer_join = bool(defer_join) and bool(overlap)
         # acting kernel placement (tvc_sac_act flags bit 2): alone on the chip it is fastest with two workgroups per CU, which
         # own every register of the CU -- the update then runs AFTER the acting pass.  One workgroup per CU is ~25 % slower
         # alone but lets the update's kernels run BESIDE it, which wins at every update count (65 536 envs: 2.49 vs 2.58 ms per
@@ -55,10 +56,16 @@ class VecTrainer:
         self.share_rows = num_envs
         if self.share_cus and updates_per_step <= 1 and num_envs >= 32768 and (num_envs // 2) % 64 == 0:
             self.share_rows = num_envs // 2
+        if share_rows is not None:  # explicit split (bench: chosen at warm-up by tune_share_rows, identically on every rank)
+            self.share_rows = max(0, min(int(share_rows), num_envs))
+        self.share_tuning = None
         # the learner's stream: high HIP priority + raised wave priority inside its kernels (TVC_LEARNER_PRIO): -4 % on the step at
         # 2 and 4 updates per step, the update ends ~0.2 ms earlier at 1 (tools/ab_prio.sh)
         self._side = torch.cuda.Stream(self.device, priority=int(os.environ.get("TVC_SIDE_PRIORITY", "-1")))
         self._fork = torch.cuda.Event()
+        self._side_done = None  # timing event at the end of the learner's stream (tune_share_rows)
+        # acting_dropout = True: act in train mode like the reference's get_action (agent/...:765): Dropout live in the policy
+        self.acting_dropout = False
         # intrinsic curiosity bonus of the reference's training env (scripts/train.py:318, env/...:496-502)
         self.curiosity = None
         if enable_curiosity:
@@ -124,6 +131,7 @@ class VecTrainer:
         self._cur_pending = False
         self._cur_req_step, self._cur_lag = 0, max(1, min(8, int(every) // 2))
         self._cur_last = [0.0, 0.0, 0.0, 0.0]
+        self._cur_next = (self.steps // self._cur_every + 1) * self._cur_every  # next request: when `steps` reaches this multiple
         self.curriculum_log = []
 
     def _curriculum_tick(self):
@@ -141,8 +149,10 @@ class VecTrainer:
                 self.curriculum_log.append({"step": self.steps, "episodes": d[0], **metrics, "stage_before": before,
                                             "stage_after": self.curriculum.current_stage_idx})
             self._cur_pending = False
-        if not self._cur_pending and self.steps % self._cur_every == 0:
-            tot = self.env.episode_stats_tensor().clone()
+        # a request is due when `steps` has CROSSED a multiple of `every` (a replayed graph advances it by several steps at once)
+        if not self._cur_pending and self.steps >= self._cur_next:
+            self._cur_next = (self.steps // self._cur_every + 1) * self._cur_every
+            tot = self.env.episode_stats_tensor()
             if self.world > 1:  # every rank's driver sees the whole job's episodes, so all ranks change stage together
                 import torch.distributed as dist
                 dist.all_reduce(tot)
@@ -156,22 +166,22 @@ class VecTrainer:
         cur, nxt = self.obs[self.cur], self.obs[1 - self.cur]
         self.eps_act.normal_()
         raw = self.act_raw if self.safety is not None else self.act
+        share = self.share_cus and self._snapshot and self.share_rows > 0
         if self.hier is not None:
             self.u_goal.uniform_()
-            share = self.share_cus and self._snapshot  # the never-trained hierarchy has no snapshot to read; the update runs beside it
+            # (the never-trained hierarchy has no snapshot to read; the update runs beside it)
             a, _, _, _ = self.hier.act(cur, self.eps_act, self.u_goal, clamp=self.safety is None,
                                        share_rows=self.share_rows if share else 0)
             raw.copy_(a)
         else:
-            share = self.share_cus and self._snapshot
             k = self.share_rows if share else self.n
             if 0 < k < self.n:  # two launches over row blocks: [0, k) leaves room for the update, [k, n) takes the whole chip
                 for lo, hi, sh in ((0, k, True), (k, self.n, False)):
                     self.sac.act(cur[lo:hi], self.eps_act[lo:hi], out=(raw[lo:hi], self.mean[lo:hi], self.ls[lo:hi]),
-                                 clamp=self.safety is None, snapshot=self._snapshot, share_cus=sh)
+                                 clamp=self.safety is None, snapshot=self._snapshot, share_cus=sh, train_mode=self.acting_dropout)
             else:
                 self.sac.act(cur, self.eps_act, out=(raw, self.mean, self.ls), clamp=self.safety is None, snapshot=self._snapshot,
-                             share_cus=share)
+                             share_cus=share, train_mode=self.acting_dropout)
         if self.safety is not None:  # sees the unclamped sample; clamps its result
             self.safety.apply(cur, raw, out=self.act)
         o, rew, term, trunc, info = self.env.step(self.act, out_obs=nxt)
@@ -190,9 +200,9 @@ class VecTrainer:
         return self.sac.update(s, a, r, s2, d, self.eps1[k], self.eps2[k], all_reduce=self.sync, grad_scale=gs)
 
     def step(self, learn: bool = True):
-        if learn and self.overlap and self.steps > 0:
-            self._step_overlapped()
-        else:
+        if learn and self.steps > 0:
+            self._step_pipelined(two_streams=self.overlap)
+        else:  # first step (empty replay) / pure collection
             if self.defer_join:
                 torch.cuda.current_stream(self.device).wait_stream(self._side)
             self.collect()
@@ -203,26 +213,37 @@ class VecTrainer:
         if self.curriculum is not None and not torch.cuda.is_current_stream_capturing():
             self._curriculum_tick()  # host-side bookkeeping (event query, pinned read-back): not part of a captured graph
 
-    def _step_overlapped(self):
-        """Same work as collect() + updates_per_step x learn(), on two HIP streams.  The acting pass (large GEMMs over
-        all envs) reads a SNAPSHOT of the policy taken at the start of the step, so the whole update -- gradient phases
-        (hundreds of latency-bound batch-256 kernels), the RCCL all-reduces when data parallel, and both Adam steps --
-        runs beside it on the side stream; the two streams meet once per step.  The policy that acts during step t is
-        the one left by step t-1, exactly as in the sequential schedule.  All batches of the step are drawn before its
-        transitions are inserted (no read of a row that is being overwritten)."""
+    def _draw_update_inputs(self, cur):
+        for k in range(self.updates_per_step):
+            self.rb.sample(self.B, out=cur["batches"][k])
+            cur["eps1"][k].normal_()
+            cur["eps2"][k].normal_()
+
+    def _step_pipelined(self, two_streams: bool = True):
+        """One train step in the order every schedule shares: draw the step's batches and noise, act + env step + replay insert,
+        updates_per_step SAC updates on the batches drawn FIRST (no read of a row that is being overwritten).
+        two_streams: the acting pass (large GEMMs over all envs) reads a SNAPSHOT of the policy taken at the start of the step,
+        so the whole update -- gradient phases (hundreds of latency-bound batch-256 kernels), the RCCL all-reduces when data
+        parallel, and both Adam steps -- runs beside it on the side stream; the two streams meet once per step.  The policy that
+        acts during step t is the one left by step t-1 either way, so the sequential form (two_streams = False: live parameters,
+        everything on the current stream) does the same arithmetic on the same inputs; tests compare the two."""
         main = torch.cuda.current_stream(self.device)
-        sac, side = self.sac, self._side
+        sac = self.sac
         cur = self._sets[self.steps & 1]  # this step's update inputs; the previous update may still be reading the other set
         batches, eps1, eps2 = cur["batches"], cur["eps1"], cur["eps2"]
-        for k in range(self.updates_per_step):
-            self.rb.sample(self.B, out=batches[k])
-            eps1[k].normal_()
-            eps2[k].normal_()
+        self._draw_update_inputs(cur)
+        gs = self.sync.grad_scale if self.sync is not None else 1.0
+        if not two_streams:
+            self.collect()
+            for k in range(self.updates_per_step):
+                s, a, r, s2, d = batches[k]
+                sac.update(s, a, r, s2, d, eps1[k], eps2[k], all_reduce=self.sync, grad_scale=gs)
+            return
+        side = self._side
         # defer_join: the streams meet HERE, not at the end of the previous step: the tail of the previous update (it needs a little
         # longer than the acting launch it runs beside) overlaps the env step, the replay insert and the draws above
         main.wait_stream(side)
         sac.snapshot_policy()
-        gs = self.sync.grad_scale if self.sync is not None else 1.0
         self._fork.record(main)
         # the acting pass is enqueued FIRST: the host needs hundreds of microseconds to enqueue the ~100 learner launches
         # of an update, and the GPU would otherwise sit idle on the main stream for that long at small env counts
@@ -236,19 +257,29 @@ class VecTrainer:
             for k in range(self.updates_per_step):
                 s, a, r, s2, d = batches[k]
                 sac.update(s, a, r, s2, d, eps1[k], eps2[k], all_reduce=self.sync, grad_scale=gs)
+            if self._side_done is not None:
+                self._side_done.record(side)
         if not self.defer_join or torch.cuda.is_current_stream_capturing():
             main.wait_stream(side)  # (a captured graph must end with every forked stream joined)
 
-    def capture(self, steps_per_replay: int = 1):
+    def _check_capturable(self):
+        if self.curriculum is not None and not int(self.env.cfg.dr_enabled):
+            # a stage change reaches replayed launches through the device-resident DR record (tvc_env_set_dr_async), but the
+            # <DR> instantiation of the step kernel is chosen at launch: the driver always applies dr_enabled = 1
+            raise RuntimeError("capture with a curriculum attached needs the domain-randomised env (dr_enabled = 1) at capture time")
+
+    def capture(self, steps_per_replay: int = 2):
         """Capture `steps_per_replay` whole train steps (both streams, RNG draws included) in ONE hipGraph and return a function that
         replays it: at small env counts the ~130 launches of a step cost the host more than the device (4 096 envs: 0.77 ms per step
-        replayed, 0.80 - 0.93 ms launched eagerly, profiles/r02_f_bench_matrix.md).  Single-rank only (the RCCL all-reduces of a
-        data-parallel update are not captured); the curriculum driver's host-side bookkeeping runs after every replay."""
+        replayed, 0.80 - 0.93 ms launched eagerly, profiles/r02_f_bench_matrix.md).  Single-rank only (a data-parallel update has
+        two collectives inside: capture_segments()).  With a curriculum attached the driver's host-side bookkeeping runs after
+        every replay; a stage change reaches the replayed step kernels through the device-resident DR record."""
         if self.world > 1:
-            raise RuntimeError("VecTrainer.capture: single-rank only")
+            raise RuntimeError("VecTrainer.capture: single-rank only (use capture_segments() with data parallelism)")
         if int(steps_per_replay) % 2:
             raise ValueError("VecTrainer.capture: an even number of steps per replay (the observation double buffer flips every step)")
-        if self.steps < 2:  # the overlapped schedule starts at the second step; warm every kernel up before capturing
+        self._check_capturable()
+        if self.steps < 2:  # the pipelined schedule starts at the second step; warm every kernel up before capturing
             for _ in range(2 - self.steps):
                 self.step(True)
         torch.cuda.synchronize(self.device)
@@ -272,6 +303,154 @@ class VecTrainer:
         replay.graph = graph
         return replay
 
+    def capture_segments(self):
+        """The step as SEGMENT graphs between the collectives of a data-parallel update, valid at any world size:
+            main stream : A = [policy snapshot, act, env step, replay insert, draw the NEXT step's batches and noise]
+            side stream : B1 = [critic_grads]  -> all_reduce(critic slice) ->  B2 = [critic_apply, actor_grads]
+                          -> all_reduce(actor slice) ->  B3 = [actor_apply (Adam, fold, pack, Polyak)]
+        replayed around the two eager all_reduce calls (none at world 1): 4 graph launches + 2 collectives per step instead of ~130
+        kernel launches.  Drawing the next step's batches at the END of A is the same arithmetic as drawing them at the start of
+        the next step (both sit between the two steps' replay inserts), and lets the side stream start the update the moment the
+        step begins.  Two graph sets alternate (observation double buffer, double-buffered update inputs).  Returns step_fn()."""
+        if self.updates_per_step != 1:
+            raise ValueError("capture_segments: one update per step")
+        self._check_capturable()
+        while self.steps < 2:
+            self.step(True)
+        torch.cuda.synchronize(self.device)
+        sac, dev = self.sac, self.device
+        gs = self.sync.grad_scale if self.sync is not None else 1.0
+        # the eager loop has drawn nothing ahead: draw the inputs of the next step now, as graph A will from here on
+        self._draw_update_inputs(self._sets[self.steps & 1])
+        torch.cuda.synchronize(dev)
+        cap = torch.cuda.Stream(dev)
+        sets = []
+        steps0, cur0 = self.steps, self.cur
+        for par in range(2):
+            st = steps0 + par            # parity of the step this set serves
+            upd = self._sets[st & 1]       # inputs of THIS step's update (drawn at the end of the previous A)
+            nxt = self._sets[(st + 1) & 1]
+            s, a, r, s2, d = upd["batches"][0]
+            e1, e2 = upd["eps1"][0], upd["eps2"][0]
+            graphs = {}
+
+            def cap_graph(fn):
+                g = torch.cuda.CUDAGraph()
+                cap.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(cap):
+                    with torch.cuda.graph(g, stream=cap):
+                        fn()
+                torch.cuda.current_stream(dev).wait_stream(cap)
+                return g
+
+            def seg_a():
+                sac.snapshot_policy()
+                self._snapshot = True
+                try:
+                    self.collect()
+                finally:
+                    self._snapshot = False
+                self._draw_update_inputs(nxt)
+            graphs["A"] = cap_graph(seg_a)
+            graphs["B1"] = cap_graph(lambda: sac.critic_grads(s, a, r, s2, d, e1))
+            graphs["B2"] = cap_graph(lambda: (sac.critic_apply(gs), sac.actor_grads(s, e2)))
+            graphs["B3"] = cap_graph(lambda: sac.actor_apply(gs))
+            sets.append(graphs)
+        self.cur = cur0  # capturing executed nothing (collect() flipped the double buffer twice: back where it was)
+        assert self.steps == steps0
+        torch.cuda.synchronize(dev)
+        side, sync = self._side, self.sync
+        n_pol = sac.n_policy
+
+        def step_fn():
+            main = torch.cuda.current_stream(dev)
+            g = sets[(self.steps - steps0) & 1]
+            main.wait_stream(side)        # previous update done: its parameters are what A snapshots
+            self._fork.record(main)       # ... and the batches drawn by the previous A are complete
+            g["A"].replay()
+            side.wait_event(self._fork)
+            with torch.cuda.stream(side):
+                g["B1"].replay()
+                if sync is not None:
+                    sync(sac.grads[n_pol:])
+                g["B2"].replay()
+                if sync is not None:
+                    sync(sac.grads[:n_pol])
+                g["B3"].replay()
+                if self._side_done is not None:
+                    self._side_done.record(side)
+            if not self.defer_join:
+                main.wait_stream(side)
+            self.cur = 1 - self.cur
+            self.steps += 1
+            if self.curriculum is not None:
+                self._curriculum_tick()
+
+        step_fn.graphs = sets
+        return step_fn
+
+    def uses_rows_kernel(self) -> bool:
+        """does the acting pass of this trainer go through the one-launch kernels (whose CU-sharing form the split chooses)?"""
+        return int(self.sac.cfg.family) == 0 and self.n >= 12288 and not self.acting_dropout
+
+    def tune_share_rows(self, candidates=None, steps: int = 6):
+        """Choose how many rows the acting kernel handles in its CU-sharing form (the rest run in the exclusive form) from MEASURED
+        step times: each candidate split runs `steps` real train steps (2 more to settle) between HIP events on the main stream with
+        the join inside, the time is maximised over the ranks of a data-parallel job (so it includes the collectives, and every rank
+        picks the same split), and the fastest wins.  Also records the update's end-of-stream slack at the chosen split: how long
+        before the end of the step's main-stream work the learner's stream went idle (negative: the update is the critical path)."""
+        n = self.n
+        if not (self.share_cus and self.overlap) or self.hier is not None:
+            return None
+        if candidates is None:
+            q = max(64, (n // 8) // 64 * 64)
+            candidates = sorted({0, *[min(n, k * q) for k in range(1, 8)], n})
+        while self.steps < 2:
+            self.step(True)
+        results = []
+        dj = self.defer_join
+        self.defer_join = False
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        try:
+            for k in candidates:
+                self.share_rows = int(k)
+                for _ in range(2):
+                    self.step(True)
+                torch.cuda.synchronize(self.device)
+                e0.record()
+                for _ in range(steps):
+                    self.step(True)
+                e1.record()
+                torch.cuda.synchronize(self.device)
+                us = e0.elapsed_time(e1) * 1e3 / steps
+                if self.world > 1:
+                    import torch.distributed as dist
+                    t = torch.tensor([us], dtype=torch.float64, device=self.device)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    us = float(t.item())
+                results.append((int(k), us))
+            best = min(results, key=lambda kv: kv[1])
+            self.share_rows = best[0]
+            # slack of the learner's stream at the chosen split
+            self._side_done = torch.cuda.Event(enable_timing=True)
+            m_end = torch.cuda.Event(enable_timing=True)
+            self.defer_join = True
+            slacks = []
+            for _ in range(4):
+                self.step(True)
+                m_end.record()
+                torch.cuda.synchronize(self.device)
+                slacks.append(self._side_done.elapsed_time(m_end) * 1e3)  # > 0: the update ended before the main stream did
+            self._side_done = None
+        finally:
+            self.defer_join = dj
+        self.share_tuning = {"chosen_share_rows": best[0], "us_per_step": best[1],
+                             "candidates": [{"share_rows": k, "us_per_step": us} for k, us in results],
+                             "update_end_slack_us": sorted(slacks)[len(slacks) // 2],
+                             "note": "slack = main-stream end minus learner-stream end of a step (median of 4), measured after the "
+                                     "choice; times are max over ranks"}
+        return self.share_tuning
+
     # -- true resume (the reference's --resume is a stub, scripts/train.py:904-907): learner, env SoA state, current
     #    observations, replay contents and counters, and the device RNG state
     def state_dict(self):
@@ -292,6 +471,16 @@ class VecTrainer:
                                                         ("hier_high", self.hier.high if self.hier is not None else None),
                                                         ("hier_low", self.hier.low if self.hier is not None else None))
                          if v is not None},
+            # device-side episode statistics (running return per env + totals) and the curriculum driver's position: without them
+            # the first episode finished after a resume carries a partial return and the driver restarts from its constructor stage
+            "episode_stats": self.env.episode_stats_state(),
+            "curriculum": None if self.curriculum is None else {
+                "stage_idx": int(self.curriculum.current_stage_idx), "step": int(self.curriculum.current_step),
+                "transitions": [int(x) for x in self.curriculum.stage_transition_steps],
+                "completed": [bool(st.completed) for st in self.curriculum.stages],
+                "last_totals": [float(x) for x in self._cur_last]},
+            "act_counters": {"sac": self.sac.act_counter(),
+                             "hier_low": self.hier.low.act_counter() if self.hier is not None else 0},
         }
 
     def load_state_dict(self, sd):
@@ -321,6 +510,22 @@ class VecTrainer:
                 net.params.copy_(saved[k])
         if self.hier is not None:
             self.hier.low.sync_derived()
+        self.env.load_episode_stats_state(sd.get("episode_stats") or {})
+        cs = sd.get("curriculum")
+        if cs is not None and self.curriculum is not None:
+            drv = self.curriculum
+            drv.current_stage_idx, drv.current_step = int(cs["stage_idx"]), int(cs["step"])
+            drv.stage_transition_steps = list(cs["transitions"])
+            for st, done in zip(drv.stages, cs["completed"]):
+                st.completed = bool(done)
+            drv._apply()
+            self._cur_last = [float(x) for x in cs["last_totals"]]
+            self._cur_pending = False
+            self._cur_next = (self.steps // self._cur_every + 1) * self._cur_every
+        ac = sd.get("act_counters") or {}
+        self.sac.set_act_counter(int(ac.get("sac", 0)))
+        if self.hier is not None:
+            self.hier.low.set_act_counter(int(ac.get("hier_low", 0)))
         torch.cuda.set_rng_state(sd["rng"], self.device)
         torch.cuda.synchronize(self.device)
 
@@ -353,8 +558,10 @@ def bench_train(args, world, rank, device, n_envs=None):
     tr = VecTrainer(n, device=device, family=family, batch_size=256, replay_capacity=1_000_000, seed=42,
                     rank=rank, world=world, updates_per_step=utd, overlap=not getattr(args, "no_overlap", False),
                     share_cus={"auto": None, "on": True, "off": False}[getattr(args, "share_cus", "auto")],
+                    defer_join=True,  # the bench synchronises the device around its timed region
+                    share_rows=None if int(getattr(args, "share_rows", -1)) < 0 else int(args.share_rows),
                     enable_hierarchical=shipped, enable_safety=shipped, enable_curiosity=shipped, **env_over)
-    tr.defer_join = True  # the bench synchronises the device around its timed region
+    tr.acting_dropout = bool(getattr(args, "acting_dropout", False)) and tr.dropout_p > 0
     if stage is not None:  # the curriculum driver reads device-side episode statistics and owns the stage from here on
         from .curriculum import CurriculumDriver
         from .env import default_curriculum_config
@@ -362,6 +569,9 @@ def bench_train(args, world, rank, device, n_envs=None):
         drv.current_stage_idx = stage - 1
         drv.current_step = sum(s.duration_steps for s in drv.stages[:stage - 1])
         tr.attach_curriculum(drv, every=50, min_episodes=50)
+    tuning = None
+    if int(getattr(args, "share_rows", -1)) < 0 and utd == 1 and not shipped and tr.share_cus and tr.overlap and tr.uses_rows_kernel():
+        tuning = tr.tune_share_rows()  # measured split, identical on every rank (times are maximised over the ranks)
     fam = "reference shapes (seq-len-1 transformer actor 2.26M trainable params, 512/256 GELU+LN critics)" if family == 0 \
         else "256x256 ReLU MLP actor/critics"
     return {"step_fn": lambda k: tr.step(True), "env": tr.env, "trainer": tr,
@@ -370,6 +580,8 @@ def bench_train(args, world, rank, device, n_envs=None):
                                                       "dropout_in_update": tr.dropout_p,
                                                       "acting_kernel_shares_cus": tr.share_cus,
                                                       "acting_rows_in_sharing_form": tr.share_rows if tr.share_cus else 0,
+                                                      "share_rows_tuning": tuning,
+                                                      "acting_dropout": tr.acting_dropout,
                                                       "acting": "hierarchical goal policy + safety layer + curiosity bonus (shipped config.yaml)"
                                                       if shipped else "SAC policy",
                                                       "reward_history_window": int(tr.env.cfg.distinct_window),
