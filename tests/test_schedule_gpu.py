@@ -25,13 +25,14 @@ def _randomise_vectors(sac, seed):
     sac.sync_derived()
 
 
-@pytest.mark.parametrize("n,k,use_se", [(65536, 32768, 0), (65536 - 37, 20000, 0), (16384 + 5, 4096 + 64, 1)])
+@pytest.mark.parametrize("n,k,use_se", [(65536, 32768, 0), (65536 - 37, 20000, 0), (32768 + 5, 16384 + 64, 1)])
 def test_snapshot_split_sharing_form_is_bit_equal_to_the_live_call(n, k, use_se):
     """NativeSAC.act on rows [0, k) in the CU-sharing form + rows [k, n) in the exclusive form, both on the policy SNAPSHOT
     (what VecTrainer's two-stream step launches), against act() on the live parameters: bit for bit; both against the
     restatement on sampled rows.  Then the live parameters change: the snapshot calls must keep answering with the old policy."""
     from tvc_ai_amd.agent import NativeSAC, sac_cfg
     torch.set_num_threads(8)
+    assert min(k, n - k) >= 12288  # both parts and the whole go through the same (one-launch, 64 rows per workgroup) kernel
     obs_dim = 14 if use_se else 10
     sac = NativeSAC(sac_cfg(0, obs_dim=obs_dim, batch_size=64, max_act_rows=65536, use_se=use_se), seed=17)
     _randomise_vectors(sac, 5)

@@ -12,8 +12,8 @@ with open(sys.argv[1]) as f:
         g = "x".join(str(int(r[f"Grid_Size_{a}"]) // max(1, int(r[f"Workgroup_Size_{a}"]))) for a in "XYZ")
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), g))
 rows.sort()
-# an update ends with the polyak kernel; take the last complete one
-ends = [i for i, r in enumerate(rows) if "polyak" in r[2]]
+# an update starts with update_prep_kernel; take the last complete one
+ends = [i - 1 for i, r in enumerate(rows) if "update_prep" in r[2]]
 lo, hi = ends[-2] + 1, ends[-1] + 1
 seq = rows[lo:hi]
 t0 = seq[0][0]

@@ -397,11 +397,44 @@ struct PackTile { long src; int ld, k0, kvalid, from_ov, blocked; };   // src: f
 // blocked = 1: a 16-row matrix, n-block kt of the image = its 16 rows at k-tile kt (image[q][16 kt + j] = W[j][16 kt + 4 q ..]);
 // blocked = 2: a deep tile, 32 k x 128 rows: image[a][q][n] = W[n][k0 + 16 a + 4 q ..] for n < 128
 struct PackVec { long src; int dst, count, from_ov; };
+// The output head behind the second LayerNorm of the policy head is folded into running sums (actor_rows_body): the parts of that
+// fold that do not depend on the input are made by the LAST workgroup of pack_actor_kernel, once per policy update, into the
+// vector tail:
+//   +3584  gW[o][n] = gamma6[n] W8[o][n]   (o < 2A, else 0)      +5632  E[o] = sum_n beta6[n] W8[o][n] + b8[o]      +5636  G[o] = sum_n gW[o][n]
+struct HeadPack { const float* gamma6; const float* beta6; const float* W8; const float* b8; int n_out; float* tail; };
+__device__ __forceinline__ void pack_head(const HeadPack& hp, float (*red)[4][256]) {
+    const int tid = threadIdx.x;
+    for (int o = 0; o < 4; ++o) {
+        float g = 0.0f, e = 0.0f;
+        for (int n = tid; n < 512; n += 256) {
+            const float w = o < hp.n_out ? hp.W8[o * 512 + n] : 0.0f;
+            const float gw = hp.gamma6[n] * w;
+            hp.tail[3584 + 512 * o + n] = gw;
+            g += gw;
+            e = fmaf(hp.beta6[n], w, e);
+        }
+        red[0][o][tid] = g; red[1][o][tid] = e;
+    }
+    __syncthreads();
+    if (tid < 8) {
+        const int o = tid & 3, which = tid >> 2;
+        float s = 0.0f;
+        for (int i = 0; i < 256; ++i) s += red[which][o][i];
+        if (which == 0) hp.tail[5636 + o] = s;
+        else hp.tail[5632 + o] = s + (o < hp.n_out ? hp.b8[o] : 0.0f);
+    }
+}
 __global__ void __launch_bounds__(256) pack_actor_kernel(const float* __restrict__ P, const float* __restrict__ OV,
                                                          const PackTile* __restrict__ tiles, int n_tiles,
-                                                         const PackVec* __restrict__ vecs, float4* __restrict__ out_tiles,
-                                                         float* __restrict__ out_vec) {
+                                                         const PackVec* __restrict__ vecs, int n_vecs, float4* __restrict__ out_tiles,
+                                                         float* __restrict__ out_vec, HeadPack hp, Ticks tk) {
+    __shared__ float red[2][4][256];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (b == n_tiles + n_vecs) {  // last workgroup: the folded output head (+ the riders of this launch)
+        if (tid == 0) run_ticks(tk);
+        pack_head(hp, red);
+        return;
+    }
     if (b < n_tiles) {
         const PackTile t = tiles[b];
         const float* base = (t.from_ov ? OV : P) + t.src;
@@ -427,35 +460,6 @@ __global__ void __launch_bounds__(256) pack_actor_kernel(const float* __restrict
         const PackVec e = vecs[b - n_tiles];
         const float* src = (e.from_ov ? OV : P) + e.src;
         for (int i = tid; i < e.count; i += 256) out_vec[e.dst + i] = src[i];
-    }
-}
-
-// The output head behind the second LayerNorm of the policy head is folded into running sums (actor_rows_body): the parts of that
-// fold that do not depend on the input are made here, once per policy update, into the vector tail:
-//   +3584  gW[o][n] = gamma6[n] W8[o][n]   (o < 2A, else 0)      +5632  E[o] = sum_n beta6[n] W8[o][n] + b8[o]      +5636  G[o] = sum_n gW[o][n]
-__global__ void __launch_bounds__(256) pack_head_kernel(const float* __restrict__ gamma6, const float* __restrict__ beta6,
-                                                        const float* __restrict__ W8, const float* __restrict__ b8, int n_out,
-                                                        float* __restrict__ tail) {
-    __shared__ float red[2][4][256];
-    const int tid = threadIdx.x;
-    for (int o = 0; o < 4; ++o) {
-        float g = 0.0f, e = 0.0f;
-        for (int n = tid; n < 512; n += 256) {
-            const float w = o < n_out ? W8[o * 512 + n] : 0.0f;
-            const float gw = gamma6[n] * w;
-            tail[3584 + 512 * o + n] = gw;
-            g += gw;
-            e = fmaf(beta6[n], w, e);
-        }
-        red[0][o][tid] = g; red[1][o][tid] = e;
-    }
-    __syncthreads();
-    if (tid < 8) {
-        const int o = tid & 3, which = tid >> 2;
-        float s = 0.0f;
-        for (int i = 0; i < 256; ++i) s += red[which][o][i];
-        if (which == 0) tail[5636 + o] = s;
-        else tail[5632 + o] = s + (o < n_out ? b8[o] : 0.0f);
     }
 }
 

@@ -58,6 +58,48 @@ __device__ __forceinline__ float act_grad(float z, int act) {
     return act == ACT_GELU ? gelu_grad(z) : (act == ACT_RELU ? (z > 0.0f ? 1.0f : 0.0f) : 1.0f);
 }
 
+// ------------------------------------------------------------------ kernel arguments: one miss, not five
+// A kernel starts with a cold scalar cache, and hipcc fetches by-value kernel arguments lazily, basic block by basic block: the
+// split-K GEMM's 420-byte argument struct arrived in FIVE dependent s_load rounds (~900 cycles each, tools/gemm_stamps.py) before
+// its first operand load could even be addressed.  This touches every 64-byte line of the argument segment at once at kernel
+// entry (one dword per line, results unused): the compiler's own loads then hit in the scalar cache.
+#define TVC_KA4(base) "s_load_dword %0, %4, " #base "+0x0\n\ts_load_dword %1, %4, " #base "+0x40\n\t" \
+                      "s_load_dword %2, %4, " #base "+0x80\n\ts_load_dword %3, %4, " #base "+0xc0\n\t"
+template <int BYTES>
+__device__ __forceinline__ void warm_kernargs() {
+    auto ka = __builtin_amdgcn_kernarg_segment_ptr();
+    constexpr int LINES = (BYTES + 63) / 64 + 1;  // + the first line of the implicit arguments (grid size) behind the explicit ones
+    static_assert(LINES <= 16, "argument struct larger than expected");
+    unsigned d0, d1, d2, d3;
+    // ONE asm statement (loads + the wait): the destinations are scratch, reused by every group, and must not be handed to other
+    // values while a load is still in flight
+    if (LINES > 12)
+        asm volatile(TVC_KA4(0x300) TVC_KA4(0x200) TVC_KA4(0x100) TVC_KA4(0x0) "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3) : "s"(ka));
+    else if (LINES > 8)
+        asm volatile(TVC_KA4(0x200) TVC_KA4(0x100) TVC_KA4(0x0) "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3) : "s"(ka));
+    else if (LINES > 4)
+        asm volatile(TVC_KA4(0x100) TVC_KA4(0x0) "s_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3) : "s"(ka));
+    else
+        asm volatile(TVC_KA4(0x0) "s_waitcnt lgkmcnt(0)" : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3) : "s"(ka));
+}
+
+// ------------------------------------------------------------------ device-resident clocks
+// The Adam step counter t and the running powers b1^t, b2^t (double) live on the device, so a captured update keeps counting.
+// adam_dev_kernel only READS the clock (every workgroup derives the step's bias corrections from it); the clock advances in a
+// single thread of a LATER launch of the same chain (the sampling kernel of the actor phase for the critics' clock, the weight
+// packing for the actor's), so an optimiser step costs one launch, not two.
+struct AdamClock { double b1t, b2t; int step; int pad; };
+__device__ __forceinline__ void adam_clock_advance(AdamClock* clk, float b1, float b2) {
+    clk->b1t = clk->b1t * (double)b1; clk->b2t = clk->b2t * (double)b2; clk->step += 1;
+}
+struct Ticks { AdamClock* clk; float b1, b2; int* ctr; };  // optional riders of a launch: advance an Adam clock / a call counter
+__device__ __forceinline__ void run_ticks(const Ticks& tk) {
+    if (tk.clk) adam_clock_advance(tk.clk, tk.b1, tk.b2);
+    if (tk.ctr) *tk.ctr += 1;
+}
+
 // ------------------------------------------------------------------ dropout (update path only)
 // nn.Dropout(p) of the reference's train-mode nets (agent/multi_algorithm_agent.py:141,159,163,600,604 and the encoder
 // layers' dropout / dropout1 / dropout2 / attention-weight dropout).  torch's Philox stream cannot be reproduced, so the
@@ -85,6 +127,18 @@ __device__ __forceinline__ float drop_factor(const DropArgs& d, unsigned key, in
     return b >= d.thresh ? d.scale : 0.0f;
 }
 
+// LayerNorm folded into the A-operand load of the Linear that consumes it (update path, gemm_skinny_ln_kernel): the GEMM reads the
+// norm's INPUT rows, computes their statistics in registers (exact two-pass, like layernorm_fwd_kernel), normalises, applies the
+// norm's output dropout, and multiplies.  The workgroups of column tile 0 also write what the backward pass and later readers
+// of the norm's output need: mean / rstd per row and the materialised output Y (after dropout).  gamma2 != nullptr: two norms
+// back to back (norm2 -> feature_norm of the policy): Y1 / mean / rstd belong to the first, Y / mean2 / rstd2 to the second.
+struct LnA {
+    const float* gamma; const float* beta; const float* gamma2; const float* beta2;  // [K], group stride gP
+    float* mean; float* rstd; float* mean2; float* rstd2;                            // [M] or nullptr, group stride gS
+    float* Y; float* Y1;                                                             // [M, K] or nullptr, group stride gY
+    long gP, gS, gY;
+};
+
 // ------------------------------------------------------------------ GEMM  C[M,N] = epi(sum_k A(m,k) * B(n,k))
 struct GemmArgs {
     const float* A;   // A_KC: A[m*lda + k]   else A[k*lda + m]
@@ -106,7 +160,29 @@ struct GemmArgs {
     long gA, gA2, gB, gC, gBias, gZ, gR, gDZ, gCol;
     DropArgs drop;          // forward: dropout on act(.) before the residual add   (split-K kernel only)
     DropArgs dmask;         // dgrad: the producer's dropout mask, applied before its act' (split-K kernel only)
+    LnA lnA;                // lnA.gamma != nullptr: A = LayerNorm(A rows) computed in the operand load (gemm_skinny_ln_kernel)
+    DropArgs lnDrop;        // ... followed by that norm's output dropout
+#ifdef TVC_GEMM_STAMPS
+    unsigned long long* stamps;  // timing build only (tools/gemm_stamps.py): 8 x s_memtime per workgroup
+#endif
 };
+#ifdef TVC_GEMM_STAMPS
+// timing build: stamps are kept in scalar registers and written once, at the very end (a store per stamp would sit in the memory
+// pipeline in front of the accesses being timed)
+#define TVC_STAMP_DECL unsigned long long tvc_st[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TVC_STAMP(g, slot) tvc_st[slot] = __builtin_amdgcn_s_memtime()
+#define TVC_STAMP_FLUSH(g)                                                                                          \
+    do {                                                                                                             \
+        if ((g).stamps && threadIdx.x == 0) {                                                                        \
+            unsigned long long* o_ = (g).stamps + 8 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)); \
+            for (int i_ = 0; i_ < 8; ++i_) o_[i_] = tvc_st[i_];                                                      \
+        }                                                                                                            \
+    } while (0)
+#else
+#define TVC_STAMP_DECL do {} while (0)
+#define TVC_STAMP(g, slot) do {} while (0)
+#define TVC_STAMP_FLUSH(g) do {} while (0)
+#endif
 
 constexpr int GBM = 64, GBN = 64, GBK = 16, GLD = GBK + 4;  // LDS rows padded to 20 floats (16-B aligned)
 constexpr int THIN_K = 16, THIN_ROWS = 8;  // widest input handled by the plain-FMA input-layer kernels; rows per workgroup
@@ -561,6 +637,261 @@ __global__ void __launch_bounds__(256) gemm_rowln_kernel(RowLnArgs g) {
 // FAST: every fragment load is in range and 16-byte aligned (M, N multiples of 32, K a multiple of 16, k-contiguous
 // operands with ld % 4 == 0): loads are unconditional.  Otherwise addresses are clamped into range and the value is
 // zero-selected AFTER the load -- never a branch around a load (hipcc would wait vmcnt(0) per element, guide 5 item 4c).
+// What a batch-256 GEMM launch costs is latency, not arithmetic (in-kernel stamps, profiles/r03_b_gemm_stamps.md: ~2.3 us until the
+// first operands land in eight cold L2s, 1.0 us of MFMAs, and 1.5 us for ONE more dependent miss when the epilogue only then asks
+// for its bias / residual / act' operands).  Two remedies:
+//  * xcd_tile: workgroups are dealt round-robin over the 8 XCDs, each with its own (just invalidated) L2; the tiles of one XCD are
+//    made a compact r x c block of the output, so that an XCD fetches M/r rows of A and N/c rows of B instead of nearly all of both;
+//  * SkinnyPre: every epilogue operand of this thread's four output columns is requested at kernel entry, beside the MFMA operands.
+__device__ __forceinline__ void xcd_tile(int lin, int gx, int gy, int& bx, int& by) {
+    bx = lin % gx; by = lin / gx;
+    const int total = gx * gy;
+    if ((total & 7) != 0) return;
+    int rg = 0, best = 1 << 30;
+#pragma unroll
+    for (int r = 8; r >= 1; r >>= 1) {
+        const int c = 8 / r;
+        if ((gy % r) == 0 && (gx % c) == 0) {
+            const int cost = gy / r + gx / c;
+            if (cost < best) { best = cost; rg = r; }
+        }
+    }
+    if (rg == 0) return;
+    const int cg = 8 / rg, tw = gx / cg, th = gy / rg;
+    const int xcd = lin & 7, idx = lin >> 3;
+    by = (xcd / cg) * th + idx / tw;
+    bx = (xcd % cg) * tw + idx % tw;
+}
+struct SkinnyPre { float bias[4], rt[4], radd[4], dz[4]; };
+__device__ __forceinline__ SkinnyPre skinny_prefetch(const GemmArgs& g, long z, int m0, int n0) {
+    SkinnyPre p;
+    const int tid = threadIdx.x, rl = tid >> 3, cl = (tid & 7) * 4;
+    const int row = min(m0 + rl, g.M - 1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = min(n0 + cl + c, g.N - 1);
+        const long o = (long)row * g.ldc + col;
+        p.bias[c] = g.bias ? g.bias[z * g.gBias + col] : 0.0f;
+        p.rt[c] = g.rowtab ? g.rowtab[(long)(row % g.rowtab_rows) * g.N + col] : 0.0f;
+        p.radd[c] = g.Radd ? g.Radd[z * g.gR + o] : 0.0f;
+        p.dz[c] = g.dactZ ? g.dactZ[z * g.gDZ + o] : 0.0f;
+    }
+    return p;
+}
+// FAST launches (every tile full, K a multiple of 256, every pointer 16-byte aligned): the thread's four output columns are one
+// float4 everywhere.  Loads are UNCONDITIONAL (an absent operand reads a valid dummy address and is zero-selected afterwards):
+// hipcc answers a load inside a branch, a register zeroed behind a load, or a load behind a possibly aliasing store with a full
+// s_waitcnt vmcnt(0) -- the first version of this kernel spent 8 serial round trips on its 16 operand loads and 4 more on its 4
+// dword stores (6 000 + 2 700 of its 12 000 cycles, tools/gemm_stamps.py).
+struct SkinnyPre4 { float4 bias, rt, radd, dz; unsigned kdrop, kmask; };
+__device__ __forceinline__ float4 ld4_or_zero(const float* p, const float* dummy, long off) {
+    const float4 v = *reinterpret_cast<const float4*>(p ? p + off : dummy);
+    return p ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ SkinnyPre4 skinny_prefetch4(const GemmArgs& g, long z, int m0, int n0) {
+    SkinnyPre4 p;
+    const int tid = threadIdx.x, row = m0 + (tid >> 3), col = n0 + (tid & 7) * 4;
+    const long o = (long)row * g.ldc + col;
+    const float* dummy = g.B;  // valid, 16-byte aligned
+    p.bias = ld4_or_zero(g.bias, dummy, z * g.gBias + col);
+    p.rt = ld4_or_zero(g.rowtab, dummy, g.rowtab ? (long)(row % g.rowtab_rows) * g.N + col : 0);
+    p.radd = ld4_or_zero(g.Radd, dummy, z * g.gR + o);
+    p.dz = ld4_or_zero(g.dactZ, dummy, z * g.gDZ + o);
+    const int* ic = reinterpret_cast<const int*>(dummy);
+    const unsigned c1 = (unsigned)*(g.drop.ctr ? g.drop.ctr : ic), c2 = (unsigned)*(g.dmask.ctr ? g.dmask.ctr : ic);
+    p.kdrop = drop_mix(c1 ^ (g.drop.site * 0x9E3779B9u) ^ ((unsigned)z * 0x7F4A7C15u) ^ g.drop.seed);
+    p.kmask = drop_mix(c2 ^ (g.dmask.site * 0x9E3779B9u) ^ ((unsigned)z * 0x7F4A7C15u) ^ g.dmask.seed);
+    return p;
+}
+__device__ __forceinline__ void skinny_epilogue4(const GemmArgs& g, const f32x4 (&acc)[2][2], float (*red)[32 * 33], int m0, int n0, long z,
+                                                 const SkinnyPre4& pre
+#ifdef TVC_GEMM_STAMPS
+                                                 , unsigned long long (&tvc_st)[8]
+#endif
+                                                 ) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][(i * 16 + (lane >> 4) * 4 + r) * 33 + j * 16 + l15] = acc[i][j][r];
+    TVC_STAMP(g, 3);  // (wave 0's MFMAs are done: their results were needed for the LDS writes)
+    __syncthreads();
+    TVC_STAMP(g, 4);
+    const int rl = tid >> 3, cl = (tid & 7) * 4;  // 32 rows x 8 column quads
+    const int row = m0 + rl, col0 = n0 + cl;
+    const float bias[4] = {pre.bias.x, pre.bias.y, pre.bias.z, pre.bias.w}, rt[4] = {pre.rt.x, pre.rt.y, pre.rt.z, pre.rt.w};
+    const float radd[4] = {pre.radd.x, pre.radd.y, pre.radd.z, pre.radd.w}, dz[4] = {pre.dz.x, pre.dz.y, pre.dz.z, pre.dz.w};
+    float v[4], zv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int o = rl * 33 + cl + c;
+        float t = red[0][o] + red[1][o] + red[2][o] + red[3][o] + bias[c] + rt[c];
+        zv[c] = t;
+        t = act_f(t, g.act);
+        if (g.drop.ctr) t *= drop_factor(g.drop, pre.kdrop, row, col0 + c);
+        t += radd[c];
+        if (g.dmask.ctr) t *= drop_factor(g.dmask, pre.kmask, row, col0 + c);
+        if (g.dactZ) t *= act_grad(dz[c], g.dact);
+        v[c] = t;
+    }
+    TVC_STAMP(g, 5);
+    // stores last, back to back
+    const long oo = (long)row * g.ldc + col0;
+    if (g.Zout) *reinterpret_cast<float4*>(g.Zout + z * g.gZ + oo) = make_float4(zv[0], zv[1], zv[2], zv[3]);
+    *reinterpret_cast<float4*>(g.C + z * g.gC + oo) = make_float4(v[0], v[1], v[2], v[3]);
+    TVC_STAMP(g, 6);
+#ifdef TVC_GEMM_STAMPS
+    __builtin_amdgcn_s_waitcnt(0x0070);  // stores acknowledged
+    TVC_STAMP(g, 7);
+#endif
+    if (g.colsum) {  // column sums of the final tile (bias gradient): reduce the 32 rows through LDS
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[0][rl * 33 + cl + c] = v[c];
+        __syncthreads();
+        if (tid < 32) {
+            float sum = 0.0f;
+            for (int r = 0; r < 32; ++r) sum += red[0][r * 33 + tid];
+            atomicAdd(g.colsum + z * g.gCol + n0 + tid, sum);
+        }
+    }
+}
+// operand fragments of one chunk (4 k-steps of 16 from k-step s0 on), every load unconditional
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void skinny_load_chunk(const GemmArgs& g, const float* __restrict__ A, const float* __restrict__ B, int m0,
+                                                  int n0, int s0, int l15, int kq, float (&a)[4][2][4], float (&b)[4][2][4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k0 = (s0 + u) * 16 + kq;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = m0 + i * 16 + l15, col = n0 + i * 16 + l15;
+            if (A_KC) {
+                const float4 v = *reinterpret_cast<const float4*>(A + (long)row * g.lda + k0);
+                a[u][i][0] = v.x; a[u][i][1] = v.y; a[u][i][2] = v.z; a[u][i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[u][i][j] = A[(long)(k0 + j) * g.lda + row];
+            }
+            if (B_KC) {
+                const float4 v = *reinterpret_cast<const float4*>(B + (long)col * g.ldb + k0);
+                b[u][i][0] = v.x; b[u][i][1] = v.y; b[u][i][2] = v.z; b[u][i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[u][i][j] = B[(long)(k0 + j) * g.ldb + col];
+            }
+        }
+    }
+}
+__device__ __forceinline__ void skinny_mfma_chunk(const float (&a)[4][2][4], const float (&b)[4][2][4], f32x4 (&acc)[2][2]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i][j4], b[u][j][j4], acc[i][j], 0, 0, 0);
+}
+template <bool A_KC, bool B_KC>
+__device__ __forceinline__ void skinny_body_fast(const GemmArgs& g, int bx, int by, long z, float (*red)[32 * 33]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = by * 32, n0 = bx * 32;
+    const float* __restrict__ A = g.A + z * g.gA;
+    const float* __restrict__ B = g.B + z * g.gB;
+    const int nch = g.K >> 8;          // chunks of 4 k-steps per wave: wave w owns k-steps [4 nch w, 4 nch (w + 1))
+    const int s_begin = wave * 4 * nch;
+    const int l15 = lane & 15, kq = (lane >> 4) * 4;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    TVC_STAMP_DECL;
+    TVC_STAMP(g, 0);
+    const SkinnyPre4 pre = skinny_prefetch4(g, z, m0, n0);
+#ifdef TVC_GEMM_STAMPS
+    __builtin_amdgcn_s_waitcnt(0x0070);  // (timing build: the prefetch loads alone)
+    TVC_STAMP(g, 1);
+#endif
+    float a0[4][2][4], b0[4][2][4];
+    skinny_load_chunk<A_KC, B_KC>(g, A, B, m0, n0, s_begin, l15, kq, a0, b0);
+    if (nch == 2) {  // K = 512: both chunks in flight before the first MFMA
+        float a1[4][2][4], b1[4][2][4];
+        skinny_load_chunk<A_KC, B_KC>(g, A, B, m0, n0, s_begin + 4, l15, kq, a1, b1);
+        skinny_mfma_chunk(a0, b0, acc);
+        skinny_mfma_chunk(a1, b1, acc);
+    } else {
+#ifdef TVC_GEMM_STAMPS
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        TVC_STAMP(g, 2);
+#endif
+        skinny_mfma_chunk(a0, b0, acc);
+        for (int c = 1; c < nch; ++c) {
+            skinny_load_chunk<A_KC, B_KC>(g, A, B, m0, n0, s_begin + 4 * c, l15, kq, a0, b0);
+            skinny_mfma_chunk(a0, b0, acc);
+        }
+    }
+#ifdef TVC_GEMM_STAMPS
+    skinny_epilogue4(g, acc, red, m0, n0, z, pre, tvc_st);
+    TVC_STAMP_FLUSH(g);
+#else
+    skinny_epilogue4(g, acc, red, m0, n0, z, pre);
+#endif
+}
+// partial tiles of the four waves summed through LDS, then the shared epilogue and (optionally) bias-gradient column sums
+__device__ __forceinline__ void skinny_epilogue(const GemmArgs& g, const f32x4 (&acc)[2][2], float (*red)[32 * 33], int m0, int n0, long z,
+                                                const SkinnyPre& pre) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][(i * 16 + (lane >> 4) * 4 + r) * 33 + j * 16 + l15] = acc[i][j][r];
+    __syncthreads();
+    float* C = g.C + z * g.gC;
+    float* Zout = g.Zout ? g.Zout + z * g.gZ : nullptr;
+    float* colsum = g.colsum ? g.colsum + z * g.gCol : nullptr;
+    const unsigned kdrop = g.drop.ctr ? drop_key(g.drop, (unsigned)z) : 0u;
+    const unsigned kmask = g.dmask.ctr ? drop_key(g.dmask, (unsigned)z) : 0u;
+    const int rl = tid >> 3, cl = (tid & 7) * 4;  // 32 rows x 8 column quads
+    const int row = m0 + rl;
+    float out[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = n0 + cl + c;
+        const int o = rl * 33 + cl + c;
+        float v = red[0][o] + red[1][o] + red[2][o] + red[3][o];
+        out[c] = 0.0f;
+        if (row < g.M && col < g.N) {
+            const long oo = (long)row * g.ldc + col;
+            v += pre.bias[c] + pre.rt[c];
+            if (Zout) Zout[oo] = v;
+            v = act_f(v, g.act);
+            if (g.drop.ctr) v *= drop_factor(g.drop, kdrop, row, col);
+            v += pre.radd[c];
+            if (g.dmask.ctr) v *= drop_factor(g.dmask, kmask, row, col);
+            if (g.dactZ) v *= act_grad(pre.dz[c], g.dact);
+            C[oo] = v;
+            out[c] = v;
+        }
+    }
+    if (colsum) {  // column sums of the final tile (bias gradient): reduce the 32 rows through LDS
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[0][rl * 33 + cl + c] = out[c];
+        __syncthreads();
+        if (tid < 32 && n0 + tid < g.N) {
+            float sum = 0.0f;
+            for (int r = 0; r < 32; ++r) sum += red[0][r * 33 + tid];
+            atomicAdd(&colsum[n0 + tid], sum);
+        }
+    }
+}
 template <bool A_KC, bool B_KC, bool FAST>
 __device__ __forceinline__ void skinny_body(const GemmArgs& g, int bx, int by, long z, float (*red)[32 * 33]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -577,6 +908,7 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& g, int bx, int by, l
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int l15 = lane & 15, kq = (lane >> 4) * 4;
     constexpr int CH = 4;  // k-steps per chunk: the fragment loads of a chunk are all in flight before its 64 MFMAs
+    const SkinnyPre pre = skinny_prefetch(g, z, m0, n0);
     for (int sc = s_begin; sc < s_end; sc += CH) {
         float a[CH][2][4], b[CH][2][4];
 #pragma unroll
@@ -625,47 +957,157 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& g, int bx, int by, l
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i][j4], b[u][j][j4], acc[i][j], 0, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][(i * 16 + (lane >> 4) * 4 + r) * 33 + j * 16 + l15] = acc[i][j][r];
-    __syncthreads();
-    const GemmEpi e = gemm_epi_ptrs(g, z);
-    const int rl = tid >> 3, cl = (tid & 7) * 4;  // 32 rows x 8 column quads
-    const int row = m0 + rl;
-    float out[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int col = n0 + cl + c;
-        const int o = rl * 33 + cl + c;
-        float v = red[0][o] + red[1][o] + red[2][o] + red[3][o];
-        out[c] = 0.0f;
-        if (row < g.M && col < g.N) {
-            v = gemm_epi_value(g, e, v, row, col);
-            e.C[(long)row * g.ldc + col] = v;
-            out[c] = v;
-        }
-    }
-    if (e.colsum) {  // column sums of the final tile (bias gradient): reduce the 32 rows through LDS
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < 4; ++c) red[0][rl * 33 + cl + c] = out[c];
-        __syncthreads();
-        if (tid < 32 && n0 + tid < g.N) {
-            float sum = 0.0f;
-            for (int r = 0; r < 32; ++r) sum += red[0][r * 33 + tid];
-            atomicAdd(&e.colsum[n0 + tid], sum);
-        }
-    }
+    skinny_epilogue(g, acc, red, m0, n0, z, pre);
 }
 template <bool A_KC, bool B_KC, bool FAST>
 __global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g) {
+    warm_kernargs<sizeof(GemmArgs)>();
     TVC_LEARNER_PRIO();
     __shared__ float red[4][32 * 33];
-    skinny_body<A_KC, B_KC, FAST>(g, blockIdx.x, blockIdx.y, blockIdx.z, red);
+    int bx, by;
+    xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y, bx, by);
+    if (FAST) skinny_body_fast<A_KC, B_KC>(g, bx, by, blockIdx.z, red);
+    else skinny_body<A_KC, B_KC, false>(g, bx, by, blockIdx.z, red);
 }
+// The same 32x32 split-K tile with A = LayerNorm(X) (optionally two norms, optionally dropout) computed in the operand load:
+// K is the norm's width (256 or 512), so the four waves together stream the COMPLETE rows of their 32-row slab -- each wave holds
+// its quarter of every row (KS k-steps) in registers, row sums meet through shuffles + a 2 KB LDS exchange, and the normalised
+// fragments feed the MFMAs directly.  Saves the norm's launch and its round trip through memory: an update at batch 256 is bound
+// by the number of dependent launches (~6 us each), not by arithmetic.  Requires the FAST conditions of gemm_skinny_kernel.
+template <int KS>  // k-steps of 16 per wave: K = 64 KS (4 -> 256, 8 -> 512)
+__global__ void __launch_bounds__(256) gemm_skinny_ln_kernel(GemmArgs g) {
+    warm_kernargs<sizeof(GemmArgs)>();
+    TVC_LEARNER_PRIO();
+    __shared__ float red[4][32 * 33];
+    __shared__ float lnstat[4][4][32];  // [pass][wave][row of the slab]
+    constexpr int K = 64 * KS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bx, by;
+    xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y, bx, by);
+    const long z = blockIdx.z;
+    const int m0 = by * 32, n0 = bx * 32;
+    const float* A = g.A + z * g.gA;
+    const float* B = g.B + z * g.gB;
+    const int l15 = lane & 15, q = lane >> 4, kq = q * 4;
+    const int s_begin = wave * KS;
+    const SkinnyPre4 pre = skinny_prefetch4(g, z, m0, n0);
+    // all of this wave's A fragments: a[u][i][j] = X[m0 + 16 i + l15][16 (s_begin + u) + kq + j]
+    float a[KS][2][4];
+#pragma unroll
+    for (int u = 0; u < KS; ++u)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(A + (long)(m0 + i * 16 + l15) * g.lda + (s_begin + u) * 16 + kq);
+            a[u][i][0] = v.x; a[u][i][1] = v.y; a[u][i][2] = v.z; a[u][i][3] = v.w;
+        }
+    // every other operand is requested NOW, beside the rows: the weight fragments and the norms' gamma / beta do not depend on the
+    // statistics, and a load issued after them would be one more full miss on the critical path
+    float b[KS][2][4];
+#pragma unroll
+    for (int u = 0; u < KS; ++u)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(B + (long)(n0 + i * 16 + l15) * g.ldb + (s_begin + u) * 16 + kq);
+            b[u][i][0] = v.x; b[u][i][1] = v.y; b[u][i][2] = v.z; b[u][i][3] = v.w;
+        }
+    const LnA& ln = g.lnA;
+    const bool two = ln.gamma2 != nullptr;
+    float4 gq[2][KS], bq[2][KS];  // [norm][k-step]: gamma / beta of this lane's four k
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* gam = ((pass == 0 || !two) ? ln.gamma : ln.gamma2) + z * ln.gP;
+        const float* bet = ((pass == 0 || !two) ? ln.beta : ln.beta2) + z * ln.gP;
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            gq[pass][u] = *reinterpret_cast<const float4*>(gam + (s_begin + u) * 16 + kq);
+            bq[pass][u] = *reinterpret_cast<const float4*>(bet + (s_begin + u) * 16 + kq);
+        }
+    }
+    const bool writer = bx == 0;  // column tile 0 writes the norm's side outputs
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && !two) break;
+        float mean[2], rstd[2];
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {  // two-pass statistics like torch: mean, then the centred second moment
+            float sm[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                sm[i] = 0.0f;
+#pragma unroll
+                for (int u = 0; u < KS; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = st == 0 ? a[u][i][j] : a[u][i][j] - mean[i];
+                        sm[i] += st == 0 ? d : d * d;
+                    }
+                sm[i] += __shfl_xor(sm[i], 16);
+                sm[i] += __shfl_xor(sm[i], 32);
+                if (q == 0) lnstat[2 * pass + st][wave][i * 16 + l15] = sm[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = i * 16 + l15;
+                const float t = (lnstat[2 * pass + st][0][r] + lnstat[2 * pass + st][1][r] + lnstat[2 * pass + st][2][r] +
+                                 lnstat[2 * pass + st][3][r]) * (1.0f / (float)K);
+                if (st == 0) mean[i] = t;
+                else rstd[i] = rsqrtf(t + 1e-5f);
+            }
+        }
+        float* mo = pass == 0 ? ln.mean : ln.mean2;
+        float* ro = pass == 0 ? ln.rstd : ln.rstd2;
+        if (writer && wave == 0 && q == 0 && mo) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                mo[z * ln.gS + m0 + i * 16 + l15] = mean[i];
+                ro[z * ln.gS + m0 + i * 16 + l15] = rstd[i];
+            }
+        }
+        const bool last = pass == 1 || !two;
+        const unsigned key = (last && g.lnDrop.ctr) ? drop_key(g.lnDrop, (unsigned)z) : 0u;
+        float* yo = last ? ln.Y : ln.Y1;
+#pragma unroll
+        for (int u = 0; u < KS; ++u) {
+            const int k0 = (s_begin + u) * 16 + kq;
+            const float4 g4 = gq[pass][u], b4 = bq[pass][u];
+            const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = m0 + i * 16 + l15;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = (a[u][i][j] - mean[i]) * rstd[i] * gv[j] + bv[j];
+                    if (last && g.lnDrop.ctr) v *= drop_factor(g.lnDrop, key, row, k0 + j);
+                    a[u][i][j] = v;
+                }
+                if (writer && yo)
+                    *reinterpret_cast<float4*>(yo + z * ln.gY + (long)row * K + k0) = make_float4(a[u][i][0], a[u][i][1], a[u][i][2], a[u][i][3]);
+            }
+        }
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < KS; ++u)
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i][j4], b[u][j][j4], acc[i][j], 0, 0, 0);
+#ifdef TVC_GEMM_STAMPS
+    unsigned long long tvc_st[8];
+    skinny_epilogue4(g, acc, red, m0, n0, z, pre, tvc_st);
+#else
+    skinny_epilogue4(g, acc, red, m0, n0, z, pre);
+#endif
+}
+
 // Backward of one Linear at batch size in ONE launch: workgroups [0, nw) compute dW = dZ^T X (both operands
 // m-contiguous), the others dX = dZ W (+ residual gradient, act', bias column sums).  The two products share dZ and
 // nothing else, so running them side by side halves the launch count of the backward chain (latency-bound, H5).
@@ -675,14 +1117,22 @@ struct GemmPair {
 };
 template <bool FAST>
 __global__ void __launch_bounds__(256) gemm_skinny_bwd_kernel(GemmPair p) {
+    warm_kernargs<sizeof(GemmPair)>();
     TVC_LEARNER_PRIO();
     __shared__ float red[4][32 * 33];
-    int b = blockIdx.x;
+    int b = blockIdx.x, bx, by;
+    const bool al = (p.nw & 7) == 0 && ((gridDim.x - p.nw) & 7) == 0;  // both regions start on an XCD-0 workgroup
     if (b < p.nw) {
-        skinny_body<false, false, FAST>(p.w, b % p.w_tiles_x, b / p.w_tiles_x, blockIdx.z, red);
+        if (al) xcd_tile(b, p.w_tiles_x, p.nw / p.w_tiles_x, bx, by);
+        else { bx = b % p.w_tiles_x; by = b / p.w_tiles_x; }
+        if (FAST) skinny_body_fast<false, false>(p.w, bx, by, blockIdx.z, red);
+        else skinny_body<false, false, false>(p.w, bx, by, blockIdx.z, red);
     } else {
         b -= p.nw;
-        skinny_body<true, false, FAST>(p.x, b % p.x_tiles_x, b / p.x_tiles_x, blockIdx.z, red);
+        if (al) xcd_tile(b, p.x_tiles_x, (gridDim.x - p.nw) / p.x_tiles_x, bx, by);
+        else { bx = b % p.x_tiles_x; by = b / p.x_tiles_x; }
+        if (FAST) skinny_body_fast<true, false>(p.x, bx, by, blockIdx.z, red);
+        else skinny_body<true, false, false>(p.x, bx, by, blockIdx.z, red);
     }
 }
 
@@ -795,41 +1245,65 @@ __global__ void __launch_bounds__(256) thin_fwd_ln_kernel(ThinArgs a, const floa
         if (row < a.M) a.Y[(long)row * 256 + tid] = (v[r] - mean[r]) * rstd * gm + bt;
     }
 }
-// W'[o, k] = W_e[o, k] + sum_j W_ov[o, j] W_e[j, k];  b'[o] = be[o] + sum_j W_ov[o, j] be[j] + b_ov[o], be = b_e + pe0:
-// the embedding (+ PE(0)) and the first folded attention sublayer x + W_ov x + b_ov as ONE obs -> d Linear
-__global__ void __launch_bounds__(256) fold_embed_kernel(const float* __restrict__ We, const float* __restrict__ be_,
-                                                         const float* __restrict__ pe0, const float* __restrict__ Wov,
-                                                         const float* __restrict__ bov, float* __restrict__ Wout,
-                                                         float* __restrict__ bout, int d, int obs) {
+// Derived weights of the acting net that are cheap matrix-vector work, one launch over (output row o, encoder layer l):
+//   every layer:  b_ov[o] = sum_j W_o[o, j] b_v[j] + b_o[o]                                  (bias of the folded attention W_o W_v)
+//   layer 0 only: W'[o, k] = W_e[o, k] + sum_j W_ov[o, j] W_e[j, k];  b'[o] = be[o] + sum_j W_ov[o, j] be[j] + b_ov[o], be = b_e + pe0:
+//                 the embedding (+ PE(0)) and the first folded attention sublayer x + W_ov x + b_ov as ONE obs -> d Linear
+// (W_ov itself comes from the grouped GEMM launched before).  OV layout: layer l at l * ostride = [W_ov (d x d) | b_ov (d)].
+struct FoldArgs {
+    const float* P; float* OV; const float* pe0;
+    long o_w, o_b, v_b, layer_stride, ostride;   // offsets of layer 0's out_proj weight / bias, v_proj bias in P; strides per layer
+    int embed; long e_w, e_b, e_off;             // embedding fold on: offsets of W_e, b_e in P and of [W' | b'] in OV
+    int d, obs;
+};
+__global__ void __launch_bounds__(256) fold_kernel(FoldArgs a, Ticks tk) {
     TVC_LEARNER_PRIO();
-    // one workgroup per output row o; thread j carries W_ov[o, j] times row j of [W_e | be] (obs + 1 <= 17 values), then a
+    // thread j carries W_o[o, j] b_v[j] and, on layer 0, W_ov[o, j] times row j of [W_e | be] (obs + 1 <= 17 values); then a
     // workgroup reduction per value
-    __shared__ float part[4][THIN_K + 1];
-    const int o = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float acc[THIN_K + 1];
+    __shared__ float part[4][THIN_K + 2];
+    const int o = blockIdx.x, l = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = a.d, obs = a.obs;
+    if (o == 0 && l == 0 && tid == 0) run_ticks(tk);
+    const float* Wo = a.P + a.o_w + l * a.layer_stride;
+    const float* bv = a.P + a.v_b + l * a.layer_stride;
+    const float* bo = a.P + a.o_b + l * a.layer_stride;
+    float* ov = a.OV + l * a.ostride;
+    const bool emb = a.embed && l == 0;
+    const float* We = a.P + a.e_w;
+    const float* be_ = a.P + a.e_b;
+    float acc[THIN_K + 2];
 #pragma unroll
-    for (int k = 0; k <= THIN_K; ++k) acc[k] = 0.0f;
+    for (int k = 0; k < THIN_K + 2; ++k) acc[k] = 0.0f;
     for (int j = tid; j < d; j += 256) {
-        const float w = Wov[(long)o * d + j];
+        acc[THIN_K + 1] = fmaf(Wo[(long)o * d + j], bv[j], acc[THIN_K + 1]);
+        if (emb) {
+            const float w = ov[(long)o * d + j];
 #pragma unroll
-        for (int k = 0; k < THIN_K; ++k) {
-            const float e = We[(long)j * obs + min(k, obs - 1)];
-            acc[k] = fmaf(w, k < obs ? e : 0.0f, acc[k]);
+            for (int k = 0; k < THIN_K; ++k) {
+                const float e = We[(long)j * obs + min(k, obs - 1)];
+                acc[k] = fmaf(w, k < obs ? e : 0.0f, acc[k]);
+            }
+            acc[THIN_K] = fmaf(w, be_[j] + (a.pe0 ? a.pe0[j] : 0.0f), acc[THIN_K]);
         }
-        acc[THIN_K] = fmaf(w, be_[j] + (pe0 ? pe0[j] : 0.0f), acc[THIN_K]);
     }
 #pragma unroll
-    for (int k = 0; k <= THIN_K; ++k) {
+    for (int k = 0; k < THIN_K + 2; ++k) {
         float v = acc[k];
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s);
         if (lane == 0) part[wave][k] = v;
     }
     __syncthreads();
-    if (tid <= THIN_K) {
+    if (tid <= THIN_K + 1) {
         const float v = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
-        if (tid < obs) Wout[(long)o * obs + tid] = We[(long)o * obs + tid] + v;
-        if (tid == THIN_K) bout[o] = be_[o] + (pe0 ? pe0[o] : 0.0f) + v + bov[o];
+        const float bov = part[0][THIN_K + 1] + part[1][THIN_K + 1] + part[2][THIN_K + 1] + part[3][THIN_K + 1] + bo[o];
+        if (tid == THIN_K + 1) ov[(long)d * d + o] = bov;
+        if (emb) {
+            float* Wout = a.OV + a.e_off;
+            float* bout = Wout + (long)d * obs;
+            if (tid < obs) Wout[(long)o * obs + tid] = We[(long)o * obs + tid] + v;
+            if (tid == THIN_K) bout[o] = be_[o] + (a.pe0 ? a.pe0[o] : 0.0f) + v + bov;
+        }
     }
 }
 // dW[n, k] = sum_m dZ[m, n] X[m, k]: 32 weight rows per workgroup, the 8 half-waves split the batch rows

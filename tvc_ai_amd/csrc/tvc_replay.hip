@@ -3,6 +3,7 @@
 // legacy surface store_transition / len(replay_buffer) (tests/test_agent.py:99-108).
 // Layout: array of rows {s[obs], a[A], r, s2[obs], d}: a sampled row is one contiguous 96-byte segment, so a
 // batch gather is 256 short contiguous reads; insert streams whole rows.
+#include <algorithm>
 #include <new>
 
 #include "tvc_common.h"
@@ -22,52 +23,66 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// st = {head, size, sample_counter}: device-resident so that a captured hipGraph of train steps keeps advancing
-__global__ void replay_advance_kernel(long* st, long cap, int n) {
-    st[0] = (st[0] + n) % cap;
-    st[1] = st[1] + n > cap ? cap : st[1] + n;
+// st = {head, size, sample_counter, arrivals of the sample kernel, arrivals of the insert kernel}: device-resident so that a
+// captured hipGraph of train steps keeps advancing.  The counters advance inside the kernel that used them: every workgroup
+// reads them first, and the workgroup that ARRIVES LAST (one returning atomic per workgroup, at most 256 of them) writes the new
+// values -- no other workgroup can still be about to read the old ones -- so insert and sample are one launch each, not two.
+__device__ __forceinline__ bool last_arrival(unsigned* cnt) {
+    __syncthreads();  // every thread of this workgroup has read the counters (and issued its stores)
+    __shared__ unsigned last;
+    if (threadIdx.x == 0) {
+        const unsigned prev = atomicAdd(cnt, 1u);
+        last = prev == gridDim.x - 1 ? 1u : 0u;
+        if (last) *cnt = 0u;  // ready for the next launch (stream order)
+    }
+    __syncthreads();
+    return last != 0u;
 }
-__global__ void replay_tick_kernel(long* st) { st[2] += 1; }
 
-__global__ void replay_insert_kernel(float* __restrict__ buf, long cap, const long* __restrict__ st, const float* __restrict__ s,
+__global__ void replay_insert_kernel(float* __restrict__ buf, long cap, long* __restrict__ st, const float* __restrict__ s,
                                      const float* __restrict__ a, const float* __restrict__ r, const float* __restrict__ s2,
                                      const unsigned char* __restrict__ term, const unsigned char* __restrict__ trunc, int n,
                                      int no, int na) {
     const int W = 2 * no + na + 2;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)n * W) return;
-    const int row = (int)(i / W), c = (int)(i - (long)row * W);
-    const long head = st[0];
-    float v;
-    if (c < no) v = s[(long)row * no + c];
-    else if (c < no + na) v = a[(long)row * na + (c - no)];
-    else if (c == no + na) v = r[row];
-    else if (c < 2 * no + na + 1) v = s2[(long)row * no + (c - no - na - 1)];
-    else v = (term[row] | (trunc ? trunc[row] : 0)) ? 1.0f : 0.0f;  // done = terminated or truncated (scripts/train.py:582)
-    buf[((head + row) % cap) * W + c] = v;
+    const long head = st[0], size = st[1];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)n * W; i += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / W), c = (int)(i - (long)row * W);
+        float v;
+        if (c < no) v = s[(long)row * no + c];
+        else if (c < no + na) v = a[(long)row * na + (c - no)];
+        else if (c == no + na) v = r[row];
+        else if (c < 2 * no + na + 1) v = s2[(long)row * no + (c - no - na - 1)];
+        else v = (term[row] | (trunc ? trunc[row] : 0)) ? 1.0f : 0.0f;  // done = terminated or truncated (scripts/train.py:582)
+        buf[((head + row) % cap) * W + c] = v;
+    }
+    if (last_arrival(reinterpret_cast<unsigned*>(st + 4)) && threadIdx.x == 0) {
+        st[0] = (head + n) % cap;
+        st[1] = size + n > cap ? cap : size + n;
+    }
 }
 
-__global__ void replay_sample_kernel(const float* __restrict__ buf, const long* __restrict__ st, unsigned seed_lo,
+__global__ void replay_sample_kernel(const float* __restrict__ buf, long* __restrict__ st, unsigned seed_lo,
                                      unsigned seed_hi, unsigned ctr_lo, unsigned ctr_hi, int dev_counter,
                                      float* __restrict__ s, float* __restrict__ a,
                                      float* __restrict__ r, float* __restrict__ s2, float* __restrict__ d, int batch, int no,
                                      int na) {
     const int W = 2 * no + na + 2;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= batch * W) return;
-    const int b = i / W, c = i - b * W;
-    const long size = st[1];
-    if (dev_counter) { ctr_lo = (unsigned)(st[2] & 0xFFFFFFFF); ctr_hi = (unsigned)(st[2] >> 32); }
-    unsigned u[4];
-    philox4x32_10((unsigned)b, 0u, ctr_lo, ctr_hi, seed_lo, seed_hi, u);
-    const unsigned long long rnd = ((unsigned long long)u[0] << 32) | u[1];
-    const long idx = size > 0 ? (long)(rnd % (unsigned long long)size) : 0;
-    const float v = buf[idx * W + c];
-    if (c < no) s[(long)b * no + c] = v;
-    else if (c < no + na) a[(long)b * na + (c - no)] = v;
-    else if (c == no + na) r[b] = v;
-    else if (c < 2 * no + na + 1) s2[(long)b * no + (c - no - na - 1)] = v;
-    else d[b] = v;
+    const long size = st[1], counter = st[2];
+    if (dev_counter) { ctr_lo = (unsigned)(counter & 0xFFFFFFFF); ctr_hi = (unsigned)(counter >> 32); }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < batch * W; i += gridDim.x * blockDim.x) {
+        const int b = i / W, c = i - b * W;
+        unsigned u[4];
+        philox4x32_10((unsigned)b, 0u, ctr_lo, ctr_hi, seed_lo, seed_hi, u);
+        const unsigned long long rnd = ((unsigned long long)u[0] << 32) | u[1];
+        const long idx = size > 0 ? (long)(rnd % (unsigned long long)size) : 0;
+        const float v = buf[idx * W + c];
+        if (c < no) s[(long)b * no + c] = v;
+        else if (c < no + na) a[(long)b * na + (c - no)] = v;
+        else if (c == no + na) r[b] = v;
+        else if (c < 2 * no + na + 1) s2[(long)b * no + (c - no - na - 1)] = v;
+        else d[b] = v;
+    }
+    if (dev_counter && last_arrival(reinterpret_cast<unsigned*>(st + 3)) && threadIdx.x == 0) st[2] = counter + 1;
 }
 
 }  // namespace
@@ -134,9 +149,8 @@ int tvc_replay_insert(tvc_replay* rb, const float* s, const float* a, const floa
     TVC_HIP_CHECK(hipSetDevice(rb->device));
     const int W = 2 * rb->no + rb->na + 2;
     const long total = (long)n * W;
-    hipLaunchKernelGGL(replay_insert_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rb->buf,
-                       rb->cap, rb->st, s, a, r, s2, term, trunc, n, rb->no, rb->na);
-    hipLaunchKernelGGL(replay_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rb->st, rb->cap, (int)n);
+    hipLaunchKernelGGL(replay_insert_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 256)), dim3(256), 0,
+                       (hipStream_t)stream, rb->buf, rb->cap, rb->st, s, a, r, s2, term, trunc, n, rb->no, rb->na);
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -148,10 +162,9 @@ int tvc_replay_sample(tvc_replay* rb, int32_t batch, uint64_t seed, uint64_t cou
     TVC_HIP_CHECK(hipSetDevice(rb->device));
     const int W = 2 * rb->no + rb->na + 2;
     const int dev_counter = counter == UINT64_MAX;  // auto-incrementing device counter (hipGraph-replayable)
-    hipLaunchKernelGGL(replay_sample_kernel, dim3((batch * W + 255) / 256), dim3(256), 0, (hipStream_t)stream, rb->buf, rb->st,
-                       (unsigned)(seed & 0xFFFFFFFFu), (unsigned)(seed >> 32), (unsigned)(counter & 0xFFFFFFFFu),
+    hipLaunchKernelGGL(replay_sample_kernel, dim3(std::min((batch * W + 255) / 256, 256)), dim3(256), 0, (hipStream_t)stream,
+                       rb->buf, rb->st, (unsigned)(seed & 0xFFFFFFFFu), (unsigned)(seed >> 32), (unsigned)(counter & 0xFFFFFFFFu),
                        (unsigned)(counter >> 32), dev_counter, s, a, r, s2, d, batch, rb->no, rb->na);
-    if (dev_counter) hipLaunchKernelGGL(replay_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rb->st);
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -242,6 +242,13 @@ static int fuse_ln_min_rows() {  // acting batches at least this large use the f
 }
 static int g_force_variant = 0;  // diagnostics: 0 auto, 1 = 64x64 LDS-tiled, 3 = skinny split-K
 
+// FAST instantiations of the split-K kernel: full tiles, K in chunks of 256 (4 k-steps per wave), float4 everywhere
+static bool skinny_fast_ok(const GemmArgs& g) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return (g.M % 32) == 0 && (g.N % 32) == 0 && g.K >= 256 && (g.K % 256) == 0 && ((g.lda | g.ldb | g.ldc) & 3) == 0 &&
+           ((g.gA | g.gB | g.gC | g.gBias | g.gZ | g.gR | g.gDZ) & 3) == 0 && al(g.A) && al(g.B) && al(g.C) && al(g.bias) &&
+           al(g.Zout) && al(g.Radd) && al(g.dactZ) && al(g.rowtab) && g.A2 == nullptr;
+}
 static void launch_gemm(bool a_kc, bool b_kc, const GemmArgs& g, int G, hipStream_t st) {
     const bool aligned = ((g.lda & 3) == 0) && ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
@@ -250,8 +257,7 @@ static void launch_gemm(bool a_kc, bool b_kc, const GemmArgs& g, int G, hipStrea
     if ((fv == 3 || dropping || (fv == 0 && (long)g.M * g.N <= 512L * 512L)) && g.A2 == nullptr) {
         // update path (batch of a few hundred rows): latency-optimised split-K kernel
         dim3 grid((g.N + 31) / 32, (g.M + 31) / 32, G), block(256);
-        const bool fast = aligned && (g.M % 32) == 0 && (g.N % 32) == 0 && (g.K % 16) == 0 &&
-                          ((g.gA | g.gB) & 3) == 0;
+        const bool fast = aligned && skinny_fast_ok(g);
 #define TVC_SKINNY(AK, BK)                                                                               \
     do {                                                                                                 \
         if (fast) hipLaunchKernelGGL((gemm_skinny_kernel<AK, BK, true>), grid, block, 0, st, g);         \
@@ -269,6 +275,17 @@ static void launch_gemm(bool a_kc, bool b_kc, const GemmArgs& g, int G, hipStrea
     else if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, st, g);
     else if (!a_kc && b_kc) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, st, g);
     else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, st, g);
+}
+
+// Linear whose A operand is LayerNorm(A rows) (one or two norms + dropout), computed in the operand load: update path
+static void launch_gemm_ln(const GemmArgs& g, int G, hipStream_t st) {
+    dim3 grid(g.N / 32, g.M / 32, G), block(256);
+    if (g.K == 256) hipLaunchKernelGGL((gemm_skinny_ln_kernel<4>), grid, block, 0, st, g);
+    else hipLaunchKernelGGL((gemm_skinny_ln_kernel<8>), grid, block, 0, st, g);
+}
+static int fold_ln_enabled() {  // TVC_FOLD_LN=0: LayerNorms of the update run as their own launches again (A/B timing)
+    static const int v = [] { const char* e = getenv("TVC_FOLD_LN"); return e ? atoi(e) : 1; }();
+    return v;
 }
 
 // fused Linear (+act, +residual) + LayerNorm(s), 32 complete rows per workgroup; the k-tile count is a template
@@ -295,10 +312,7 @@ static void launch_rowln(const RowLnArgs& a, hipStream_t st) {
 // dW = dZ^T X and dX = dZ W of one Linear in one launch when both fit the split-K kernel's fast path
 static void launch_gemm_bwd_pair(const GemmArgs& w, const GemmArgs& x, int G, hipStream_t st) {
     auto fast = [](const GemmArgs& g) {
-        return ((g.lda & 3) == 0) && ((g.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0) &&
-               ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0) && (g.M % 32) == 0 && (g.N % 32) == 0 && (g.K % 16) == 0 &&
-               ((g.gA | g.gB) & 3) == 0 && g.A2 == nullptr &&
-               ((long)g.M * g.N <= 512L * 512L || g.drop.ctr != nullptr || g.dmask.ctr != nullptr);
+        return skinny_fast_ok(g) && ((long)g.M * g.N <= 512L * 512L || g.drop.ctr != nullptr || g.dmask.ctr != nullptr);
     };
     if (g_force_variant != 0 || !fast(w) || !fast(x)) {
         launch_gemm(false, false, w, G, st);
@@ -337,15 +351,41 @@ static DropArgs drop_args(const DropCtl* dc, int op_index, int group) {
     return d;
 }
 
+// LayerNorm ops starting at op i that can be computed inside the operand load of the Linear behind them (0 = none, 1, or 2 for
+// norm2 -> feature_norm -> Linear): the consumer must take the split-K kernel's fast path and the norm must span its whole K
+static int ln_fold_len(const NetDef& nd, int i, int M, bool dropping) {
+    if (g_force_variant != 0 || !fold_ln_enabled()) return 0;
+    const int nops = (int)nd.ops.size();
+    const Op& o = nd.ops[i];
+    if (o.type != OP_LN || (o.out_dim != 256 && o.out_dim != 512)) return 0;
+    int n = 1;
+    if (i + 1 < nops && nd.ops[i + 1].type == OP_LN && nd.ops[i + 1].src == i + 1 && nd.ops[i + 1].out_dim == o.out_dim && !o.drop) n = 2;
+    const int li = i + n;
+    if (li >= nops) return 0;
+    const Op& l = nd.ops[li];
+    if (l.type != OP_LINEAR || l.src != li || l.in_dim != o.out_dim || l.rowtab || l.mul >= 0) return 0;
+    // the consumer may not ALSO read a folded norm's output as its residual: that buffer is written by column tile 0 of the same
+    // launch (the acting net's folded attention x + W_ov x reads x twice; the training net's residual readers are later launches)
+    if (l.res >= 0 && l.res > i && l.res <= li) return 0;
+    if ((M % 32) != 0 || (l.out_dim % 32) != 0) return 0;
+    if (!dropping && (long)M * l.out_dim > 512L * 512L) return 0;  // larger products go to the LDS-tiled kernel
+    return n;
+}
+
 // forward of one net (G parameter groups batched through blockIdx.z).  X: [G?][M,in]; gX = 0 shares one input.
 static void net_forward(const NetDef& nd, const float* P, long gP, const float* X, long gX, int M, int G, Ctx& c, bool save,
                         const float* pe, int pe_rows, hipStream_t st, const float* Pext = nullptr, const In2* in2 = nullptr,
                         const DropCtl* dc = nullptr) {
+    int fold_i = -1, fold_n = 0;  // LayerNorm ops waiting to be computed inside the next Linear's operand load
     for (int i = 0; i < (int)nd.ops.size(); ++i) {
         const Op& o = nd.ops[i];
         const int out = i + 1;
         const float* in = o.src == 0 ? X : c.Y[o.src];
         const long gin = o.src == 0 ? gX : c.gY[o.src];
+        if (o.type == OP_LN && fold_n == 0) {
+            const int n = ln_fold_len(nd, i, M, dc != nullptr);
+            if (n > 0) { fold_i = i; fold_n = n; i += n - 1; continue; }
+        }
         if (thin_ok(o) && g_force_variant == 0) {  // input layer (in_dim <= 16): plain-FMA kernel, reads [X | X2] in place
             ThinArgs a = thin_input(o, in, gin, in2, M);
             a.W = (o.ext ? Pext : P) + o.w; a.bias = (o.ext ? Pext : P) + o.b; a.gW = gP; a.gB = gP;
@@ -441,7 +481,25 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
             g.gA = gin; g.gB = gP; g.gC = c.gY[out]; g.gBias = gP; g.gZ = c.gY[out];
             g.gR = o.res >= 0 ? (o.res == 0 ? gX : c.gY[o.res]) : 0;
             g.drop = drop_args(dc, i, o.drop);
-            launch_gemm(true, true, g, G, st);
+            if (fold_n > 0) {  // A = LayerNorm(s) of the rows of the first folded norm's input
+                const Op& l0 = nd.ops[fold_i];
+                const int last = fold_i + fold_n - 1;
+                g.A = c.Y[l0.src]; g.gA = c.gY[l0.src];
+                LnA& ln = g.lnA;
+                ln.gamma = P + l0.w; ln.beta = P + l0.b; ln.gP = gP; ln.gS = M;
+                ln.mean = save ? c.mean[fold_i + 1] : nullptr; ln.rstd = save ? c.rstd[fold_i + 1] : nullptr;
+                if (fold_n == 2) {
+                    ln.gamma2 = P + nd.ops[last].w; ln.beta2 = P + nd.ops[last].b;
+                    ln.mean2 = save ? c.mean[last + 1] : nullptr; ln.rstd2 = save ? c.rstd[last + 1] : nullptr;
+                    ln.Y1 = c.Y[fold_i + 1];
+                }
+                ln.Y = c.Y[last + 1]; ln.gY = c.gY[last + 1];
+                g.lnDrop = drop_args(dc, last, nd.ops[last].drop);
+                launch_gemm_ln(g, G, st);
+                fold_n = 0;
+            } else {
+                launch_gemm(true, true, g, G, st);
+            }
         } else if (o.type == OP_LN) {
             LnArgs a{};
             a.X = in; a.Y = c.Y[out]; a.gamma = P + o.w; a.beta = P + o.b;
@@ -488,8 +546,15 @@ __global__ void head_bwd_dx_act_kernel(HeadBwdArgs a, const float* Zp, long gZ, 
 
 // backward of one net.  c.dY[last] must hold the gradient w.r.t. the head output.  Gr == nullptr: data
 // gradients only (the critics inside the actor step).  Returns the input gradient in c.dY[0] when wanted.
+__global__ void critic_dgrad_headgrad_kernel(const float* __restrict__ dZ, long gZ, const float* __restrict__ W, long gW, int N, int K,
+                                             int G, int obs_dim, const float* __restrict__ head, const float* __restrict__ eps,
+                                             float* __restrict__ dhead, int M, int A, float alpha);
+// optional rider of the critics' data-gradient pass in the policy phase: the action columns of the input gradient are turned into
+// the gradient w.r.t. the policy head's output in the same launch (critic_dgrad_headgrad_kernel)
+struct HeadGradFuse { const float* head; const float* eps; float* dhead; int A, obs_dim; float alpha; bool done; };
 static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, long gG, const float* X, long gX, int M, int G,
-                         Ctx& c, bool want_input_grad, hipStream_t st, const In2* in2 = nullptr, const DropCtl* dc = nullptr) {
+                         Ctx& c, bool want_input_grad, hipStream_t st, const In2* in2 = nullptr, const DropCtl* dc = nullptr,
+                         HeadGradFuse* hg = nullptr) {
     for (int i = (int)nd.ops.size() - 1; i >= 0; --i) {
         const Op& o = nd.ops[i];
         const int out = i + 1;
@@ -552,7 +617,11 @@ static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, l
                     a.dW = Gr + o.w; a.gDW = gG;
                     hipLaunchKernelGGL(thin_wgrad_kernel, dim3((o.out_dim + 31) / 32, 1, G), dim3(256), 0, st, a);
                 }
-                if (want_input_grad) {
+                if (want_input_grad && hg && hg->A <= 2 && o.in_dim == hg->obs_dim + hg->A) {
+                    hipLaunchKernelGGL(critic_dgrad_headgrad_kernel, dim3((M + 3) / 4), dim3(256), 0, st, dZ, c.gY[out], P + o.w, gP,
+                                       o.out_dim, o.in_dim, G, hg->obs_dim, hg->head, hg->eps, hg->dhead, M, hg->A, hg->alpha);
+                    hg->done = true;
+                } else if (want_input_grad) {
                     a.W = P + o.w; a.gW = gP; a.dX = c.dY[0]; a.gDX = c.gY[0];
                     hipLaunchKernelGGL(thin_dgrad_kernel, dim3((M + 3) / 4, 1, G), dim3(256), 0, st, a);
                 }
@@ -595,10 +664,15 @@ __global__ void concat_kernel(const float* __restrict__ s, const float* __restri
 }
 
 // head output [M,2A] -> mean, clamped log_std, action = mean + exp(log_std) * eps  (agent/...:224-225, 780-782, 964-966)
-__global__ void act_ctr_tick_kernel(int* ctr) { *ctr += 1; }
+__global__ void adam_tick_kernel(AdamClock* clk, float b1, float b2) { adam_clock_advance(clk, b1, b2); }  // (rare: flush paths)
 __global__ void sample_action_kernel(const float* __restrict__ head, const float* __restrict__ eps, float* __restrict__ act,
-                                     float* __restrict__ mean_out, float* __restrict__ ls_out, int M, int A, int clamp_act) {
+                                     float* __restrict__ mean_out, float* __restrict__ ls_out, int M, int A, int clamp_act,
+                                     Ticks tk) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        if (tk.clk) adam_clock_advance(tk.clk, tk.b1, tk.b2);
+        if (tk.ctr) *tk.ctr += 1;
+    }
     if (i >= M * A) return;
     const int m = i / A, j = i - m * A;
     const float mu = head[(long)m * 2 * A + j];
@@ -610,13 +684,6 @@ __global__ void sample_action_kernel(const float* __restrict__ head, const float
     if (ls_out) ls_out[i] = ls;
 }
 
-// y = r + gamma (1 - d) min(tq1, tq2)   (agent/...:968-971)
-__global__ void td_target_kernel(const float* __restrict__ tq, const float* __restrict__ r, const float* __restrict__ d,
-                                 float* __restrict__ y, int M, float gamma) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    y[m] = r[m] + gamma * (1.0f - d[m]) * fminf(tq[m], tq[M + m]);
-}
 
 __device__ __forceinline__ float block_sum(float v) {
     __shared__ float part[4];
@@ -628,14 +695,16 @@ __device__ __forceinline__ float block_sum(float v) {
     return part[0] + part[1] + part[2] + part[3];
 }
 
-// q [2,M], y [M] -> dq = 2 (q - y) / M, losses[g] += mean((q - y)^2)   (agent/...:976-977)
-__global__ void __launch_bounds__(256) q_loss_kernel(const float* __restrict__ q, const float* __restrict__ y,
+// y = r + gamma (1 - d) min(tq1, tq2) (agent/...:968-971); q [2,M] -> dq = 2 (q - y) / M, losses[g] += mean((q - y)^2) (:976-977)
+__global__ void __launch_bounds__(256) q_loss_kernel(const float* __restrict__ q, const float* __restrict__ tq,
+                                                     const float* __restrict__ r, const float* __restrict__ d, float gamma,
                                                      float* __restrict__ dq, float* __restrict__ losses, int M) {
     const int g = blockIdx.y;
     const int m = blockIdx.x * 256 + threadIdx.x;
     float e = 0.f;
     if (m < M) {
-        const float diff = q[(long)g * M + m] - y[m];
+        const float y = r[m] + gamma * (1.0f - d[m]) * fminf(tq[m], tq[M + m]);
+        const float diff = q[(long)g * M + m] - y;
         dq[(long)g * M + m] = 2.0f * diff / (float)M;
         e = diff * diff / (float)M;
     }
@@ -680,6 +749,40 @@ __global__ void actor_head_grad_kernel(const float* __restrict__ dxin, long g_st
     dhead[(long)m * 2 * A + A + j] = pass ? (da * expf(ls) * eps[i] - alpha / (float)M) : 0.0f;
 }
 
+// ... and the same fed straight from the critics' first-layer gradients: da[m, j] = sum over both critics and their hidden units
+// of dZ[m, n] W[n, obs + j] (only the ACTION columns of the critics' input gradient are ever used), one wave per row; replaces
+// the thin dgrad launch + actor_head_grad_kernel of the policy phase
+__global__ void __launch_bounds__(256) critic_dgrad_headgrad_kernel(const float* __restrict__ dZ, long gZ, const float* __restrict__ W,
+                                                                    long gW, int N, int K, int G, int obs_dim,
+                                                                    const float* __restrict__ head, const float* __restrict__ eps,
+                                                                    float* __restrict__ dhead, int M, int A, float alpha) {
+    TVC_LEARNER_PRIO();
+    const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float acc[2] = {0.f, 0.f};
+    for (int z = 0; z < G; ++z) {
+        const float* dz = dZ + z * gZ + (long)m * N;
+        const float* w = W + z * gW;
+        for (int n = lane; n < N; n += 64) {
+            const float v = dz[n];
+            for (int j = 0; j < A; ++j) acc[j] = fmaf(v, w[(long)n * K + obs_dim + j], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o);
+    if (lane < A) {
+        const int j = lane;
+        const float da = j == 0 ? acc[0] : acc[1];
+        const float raw = head[(long)m * 2 * A + A + j];
+        const float ls = fminf(fmaxf(raw, -20.0f), 2.0f);
+        const bool pass = raw >= -20.0f && raw <= 2.0f;
+        dhead[(long)m * 2 * A + j] = da;
+        dhead[(long)m * 2 * A + A + j] = pass ? (da * expf(ls) * eps[(long)m * A + j] - alpha / (float)M) : 0.0f;
+    }
+}
+
 // First kernel of an update.  Workgroup 0: losses[0..2] = 0 and losses[3] = PhysicsInformedLoss.forward
 // (agent/...:236-285, reported only); the other workgroups stack xs2 = [s ; s'] for the single actor forward.
 __global__ void __launch_bounds__(256) update_prep_kernel(const float* __restrict__ s, const float* __restrict__ a,
@@ -716,22 +819,32 @@ __global__ void __launch_bounds__(256) update_prep_kernel(const float* __restric
 
 // torch.optim.Adam defaults written out (agent/...:623-625): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
 // p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps); g is pre-scaled by gscale (1 / world size).
-// The step counter t and the running powers b1^t, b2^t (double) live on the device, so a captured update keeps
-// counting; a one-thread kernel advances them and stores the two bias-correction factors of the step.
+// t and the powers come from the device-resident clock (AdamClock above: this launch is step clk->step + 1).
 // The gradient is zeroed once consumed, so the next update needs no memset launch.
-struct AdamClock { double b1t, b2t; int step; float bc1, bc2s; };
-__global__ void adam_tick_kernel(AdamClock* clk, float b1, float b2) {
-    const double b1t = clk->b1t * (double)b1, b2t = clk->b2t * (double)b2;
-    clk->b1t = b1t; clk->b2t = b2t; clk->step += 1;
-    clk->bc1 = (float)(1.0 - b1t);
-    clk->bc2s = (float)sqrt(1.0 - b2t);
-}
+// Workgroups from n_adam_blocks on run the Polyak update of the target critics (agent/...:1005-1010) beside the optimiser step:
+// it reads the online critics (stepped by an EARLIER launch) and touches nothing the Adam role does.
 __global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                       const AdamClock* __restrict__ clk, float gscale) {
-    const float bc1 = clk->bc1, bc2s = clk->bc2s;
+                                                       const AdamClock* __restrict__ clk, float gscale, int n_adam_blocks,
+                                                       float* __restrict__ pol_tgt, const float* __restrict__ pol_src, long pol_n,
+                                                       float tau) {
+    TVC_LEARNER_PRIO();
+    if ((int)blockIdx.x >= n_adam_blocks) {
+        const long stride = (long)(gridDim.x - n_adam_blocks) * blockDim.x;
+        for (long i = (long)(blockIdx.x - n_adam_blocks) * blockDim.x + threadIdx.x; i < pol_n; i += stride)
+            pol_tgt[i] = tau * pol_src[i] + (1.0f - tau) * pol_tgt[i];
+        return;
+    }
+    __shared__ float bc[2];
+    if (threadIdx.x == 0) {
+        const double b1t = clk->b1t * (double)b1, b2t = clk->b2t * (double)b2;
+        bc[0] = (float)(1.0 - b1t);
+        bc[1] = (float)sqrt(1.0 - b2t);
+    }
+    __syncthreads();
+    const float bc1 = bc[0], bc2s = bc[1];
     const long n4 = n >> 2;  // all four arrays are 16-byte aligned (asserted at create); n is a multiple of 4
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)n_adam_blocks * blockDim.x) {
         float4 g4 = reinterpret_cast<float4*>(g)[i], m4 = reinterpret_cast<float4*>(m)[i];
         float4 v4 = reinterpret_cast<float4*>(v)[i], p4 = reinterpret_cast<float4*>(p)[i];
         float* gp = &g4.x; float* mp = &m4.x; float* vp = &v4.x; float* pp = &p4.x;
@@ -781,6 +894,9 @@ struct tvc_sac {
     float *pack = nullptr, *snap_pack = nullptr;  // [rows_tiles * 4096 tile floats | vector section]
     PackTile* d_ptiles = nullptr;
     PackVec* d_pvecs = nullptr;
+    float* tq = nullptr;                          // [2, B]: output of the target critics (read by q_loss_kernel)
+    bool tick_pending = false;                    // the critics' Adam clock is one step behind: its advance rides on the next
+                                                  // launch of the chain (tvc_sac_actor_grads), or is flushed by whoever needs it
     bool lds_attr_set = false;                    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this handle's device
     unsigned long long* rows_stamps = nullptr;    // diagnostics: set by rows_probe around its launches
     float* P_actor() { return params; }
@@ -1041,6 +1157,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     h->mean_tmp = (float*)carve(p, (long)B * A * 4);
     h->y = (float*)carve(p, (long)B * 4);
     h->dq = (float*)carve(p, (long)B * 2 * 4);
+    h->tq = (float*)carve(p, (long)B * 2 * 4);
     h->clk = (AdamClock*)carve(p, 2 * sizeof(AdamClock));
     h->ov = (float*)carve(p, h->ov_floats * 4);
     h->snap_ov = (float*)carve(p, h->ov_floats * 4);
@@ -1079,7 +1196,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
         }
     }
     {
-        AdamClock c0[2] = {{1.0, 1.0, 0, 0.f, 0.f}, {1.0, 1.0, 0, 0.f, 0.f}};
+        AdamClock c0[2] = {{1.0, 1.0, 0, 0}, {1.0, 1.0, 0, 0}};
         he = hipMemcpy(h->clk, c0, sizeof(c0), hipMemcpyHostToDevice);
         if (he != hipSuccess) {
             (void)hipFree(h->slab);
@@ -1119,8 +1236,7 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
         net_forward(h->actor, snap ? h->snap_p : h->P_actor(), 0, obs, 0, n, 1, h->dctx, false, h->pe, h->cfg.pe_rows, st, nullptr,
                     nullptr, &dc);
         hipLaunchKernelGGL(sample_action_kernel, dim3((n * A + 255) / 256), dim3(256), 0, st, h->dctx.Y.back(), eps, act, mean, logstd,
-                           n, A, (flags & 1) ? 0 : 1);
-        hipLaunchKernelGGL(act_ctr_tick_kernel, dim3(1), dim3(1), 0, st, h->act_ctr);
+                           n, A, (flags & 1) ? 0 : 1, Ticks{nullptr, 0.f, 0.f, h->act_ctr});  // ... and advances the call counter
         TVC_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -1152,7 +1268,7 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
                 h->cfg.pe_rows, st, snap ? h->snap_ov : h->ov);
     const float* head = h->ictx.Y.back();
     hipLaunchKernelGGL(sample_action_kernel, dim3((n * A + 255) / 256), dim3(256), 0, st, head, eps, act, mean, logstd, n, A,
-                       (flags & 1) ? 0 : 1);
+                       (flags & 1) ? 0 : 1, Ticks{nullptr, 0.f, 0.f, nullptr});
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1207,6 +1323,14 @@ int tvc_debug_rows_stamps(tvc_sac* h, const float* obs, int32_t n, int32_t launc
     return 0;
 }
 
+// The critics' clock advance normally rides on the sampling kernel of the actor phase; any other entry point that finds it pending
+// issues it as its own (tiny) launch first, so the clock a kernel reads is always exact.
+static void flush_tick(tvc_sac* h, hipStream_t st) {
+    if (!h->tick_pending) return;
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, h->clk + 0, h->cfg.adam_b1, h->cfg.adam_b2);
+    h->tick_pending = false;
+}
+
 // critic input [s | a]: read in place by the thin first-layer kernels when it is at most 16 wide, else concatenated
 static const float* critic_input(tvc_sac* h, const float* s, const float* a, In2& in2, hipStream_t st) {
     const int B = h->cfg.batch_size, A = h->cfg.act_dim, no = h->cfg.obs_dim;
@@ -1242,6 +1366,7 @@ int tvc_sac_critic_grads(tvc_sac* h, const float* s, const float* a, const float
     if (check_batch_ptrs(s, a, r) || check_batch_ptrs(s2, d, eps_next)) return TVC_EINVAL;
     TVC_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
+    flush_tick(h, st);
     const tvc_sac_cfg& c = h->cfg;
     const int B = c.batch_size, A = c.act_dim, no = c.obs_dim;
     const float* pe = c.family == 0 ? h->pe : nullptr;
@@ -1256,18 +1381,23 @@ int tvc_sac_critic_grads(tvc_sac* h, const float* s, const float* a, const float
     h->actor_fwd_valid = true;
     // target: a' ~ pi(s'), y = r + gamma (1-d) min(tq1, tq2)(s', a')
     hipLaunchKernelGGL(sample_action_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, h->actx.Y.back() + (long)B * 2 * A,
-                       eps_next, h->a_tmp, (float*)nullptr, (float*)nullptr, B, A, 0);
+                       eps_next, h->a_tmp, (float*)nullptr, (float*)nullptr, B, A, 0, Ticks{nullptr, 0.f, 0.f, nullptr});
     In2 in2;
     const float* x = critic_input(h, s2, h->a_tmp, in2, st);
-    net_forward(h->critic, h->P_tq(), h->n_critic, x, 0, B, 2, h->cctx, false, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr,
-                drop_ctl(h, dcq, 120));
-    hipLaunchKernelGGL(td_target_kernel, dim3((B + 255) / 256), dim3(256), 0, st, h->cctx.Y.back(), r, d, h->y, B, c.gamma);
+    {   // the target critics' output goes to its own buffer: the online pass below reuses the context, and the loss kernel forms
+        // y = r + gamma (1 - d) min(tq1, tq2) itself
+        float* keep = h->cctx.Y.back();
+        h->cctx.Y.back() = h->tq;
+        net_forward(h->critic, h->P_tq(), h->n_critic, x, 0, B, 2, h->cctx, false, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr,
+                    drop_ctl(h, dcq, 120));
+        h->cctx.Y.back() = keep;
+    }
     // online critics on (s, a): forward (saved), loss, backward
     x = critic_input(h, s, a, in2, st);
     net_forward(h->critic, h->P_q(), h->n_critic, x, 0, B, 2, h->cctx, true, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr,
                 drop_ctl(h, dcq, 140));
-    hipLaunchKernelGGL(q_loss_kernel, dim3((B + 255) / 256, 2), dim3(256), 0, st, h->cctx.Y.back(), h->y, h->cctx.dY.back(),
-                       losses, B);
+    hipLaunchKernelGGL(q_loss_kernel, dim3((B + 255) / 256, 2), dim3(256), 0, st, h->cctx.Y.back(), h->tq, r, d, c.gamma,
+                       h->cctx.dY.back(), losses, B);
     if (!h->grads_clean[0]) TVC_HIP_CHECK(hipMemsetAsync(h->G_q(), 0, 2 * h->n_critic * sizeof(float), st));
     h->grads_clean[0] = false;
     net_backward(h->critic, h->P_q(), h->n_critic, h->G_q(), h->n_critic, x, 0, B, 2, h->cctx, false, st, in2.X2 ? &in2 : nullptr,
@@ -1276,19 +1406,24 @@ int tvc_sac_critic_grads(tvc_sac* h, const float* s, const float* a, const float
     return 0;
 }
 
-static void adam_apply(tvc_sac* h, float* p, float* g, long off, long n, int which, float gscale, hipStream_t st) {
+// one launch: Adam over [off, off + n) of the trainable buffer (+ the Polyak update of the targets as extra workgroups when asked);
+// the clock it reads is advanced by a later launch of the chain (see AdamClock)
+static void adam_apply(tvc_sac* h, float* p, float* g, long off, long n, int which, float gscale, bool polyak, hipStream_t st) {
     const tvc_sac_cfg& c = h->cfg;
-    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, h->clk + which, c.adam_b1, c.adam_b2);
     const int blocks = (int)std::min<long>((n / 4 + 255) / 256, 2048);
-    hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, st, p, g, h->adam_m + off, h->adam_v + off, n, c.lr, c.adam_b1,
-                       c.adam_b2, c.adam_eps, h->clk + which, gscale);
+    const long pn = polyak ? 2 * h->n_critic : 0;
+    const int pblocks = polyak ? (int)std::min<long>((pn + 255) / 256, 512) : 0;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks + pblocks), dim3(256), 0, st, p, g, h->adam_m + off, h->adam_v + off, n, c.lr,
+                       c.adam_b1, c.adam_b2, c.adam_eps, h->clk + which, gscale, blocks, h->P_tq(), h->P_q(), pn, c.tau);
     h->grads_clean[which] = true;
 }
 
 int tvc_sac_critic_apply(tvc_sac* h, float grad_scale, void* stream) {
     if (!h) return tvc::set_error(TVC_EINVAL, "null argument");
     TVC_HIP_CHECK(hipSetDevice(h->device));
-    adam_apply(h, h->P_q(), h->G_q(), h->n_actor, 2 * h->n_critic, 0, grad_scale, (hipStream_t)stream);
+    flush_tick(h, (hipStream_t)stream);
+    adam_apply(h, h->P_q(), h->G_q(), h->n_actor, 2 * h->n_critic, 0, grad_scale, false, (hipStream_t)stream);
+    h->tick_pending = true;  // rides on the first launch of tvc_sac_actor_grads
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1311,7 +1446,8 @@ int tvc_sac_actor_grads(tvc_sac* h, const float* s, const float* eps_new, float*
     }
     const float* head = h->actx.Y.back();
     hipLaunchKernelGGL(sample_action_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, head, eps_new, h->a_tmp, h->mean_tmp,
-                       h->ls_tmp, B, A, 0);
+                       h->ls_tmp, B, A, 0, Ticks{h->tick_pending ? h->clk + 0 : nullptr, c.adam_b1, c.adam_b2, nullptr});
+    h->tick_pending = false;
     In2 in2;
     const float* x = critic_input(h, s, h->a_tmp, in2, st);
     net_forward(h->critic, h->P_q(), h->n_critic, x, 0, B, 2, h->cctx, true, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr,
@@ -1319,10 +1455,12 @@ int tvc_sac_actor_grads(tvc_sac* h, const float* s, const float* eps_new, float*
     hipLaunchKernelGGL(actor_loss_kernel, dim3((B + 255) / 256), dim3(256), 0, st, h->cctx.Y.back(), h->ls_tmp, eps_new,
                        h->cctx.dY.back(), losses, B, A, c.alpha);
     // data gradients only through the critics (the reference also fills q.grad here, then discards it)
+    HeadGradFuse hg{head, eps_new, h->actx.dY.back(), A, no, c.alpha, false};
     net_backward(h->critic, h->P_q(), h->n_critic, nullptr, 0, x, 0, B, 2, h->cctx, true, st, in2.X2 ? &in2 : nullptr,
-                 drop_ctl(h, dcq, 160));
-    hipLaunchKernelGGL(actor_head_grad_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, h->cctx.dY[0], h->cctx.gY[0], nin, no,
-                       head, eps_new, h->actx.dY.back(), B, A, c.alpha);
+                 drop_ctl(h, dcq, 160), &hg);
+    if (!hg.done)  // (first critic layer not on the thin path: separate input-gradient and head-gradient launches)
+        hipLaunchKernelGGL(actor_head_grad_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, h->cctx.dY[0], h->cctx.gY[0], nin, no,
+                           head, eps_new, h->actx.dY.back(), B, A, c.alpha);
     if (!h->grads_clean[1]) TVC_HIP_CHECK(hipMemsetAsync(h->G_actor(), 0, h->n_actor * sizeof(float), st));
     h->grads_clean[1] = false;
     net_backward(h->actor, h->P_actor(), 0, h->G_actor(), 0, xin, 0, B, 1, h->actx, false, st, nullptr, drop_ctl(h, dca, 0));
@@ -1330,10 +1468,16 @@ int tvc_sac_actor_grads(tvc_sac* h, const float* s, const float* eps_new, float*
     return 0;
 }
 
-// W_ov = W_o W_v, b_ov = W_o b_v + b_o for every encoder layer of the acting net: two grouped launches
-static void refresh_folded(tvc_sac* h, hipStream_t st) {
+// W_ov = W_o W_v (one grouped GEMM launch), then b_ov = W_o b_v + b_o of every layer and W', b' of the folded embedding (one
+// launch), then the acting kernel's weight stream + the folded output head (one launch).  `tick`: the actor's Adam clock
+// advances in the LAST launch issued here (or in its own launch when there is nothing to derive).
+static void refresh_folded(tvc_sac* h, hipStream_t st, AdamClock* tick) {
     const FoldInfo& f = h->fold;
-    if (f.layers == 0) return;
+    const tvc_sac_cfg& c = h->cfg;
+    if (f.layers == 0) {
+        if (tick) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, tick, c.adam_b1, c.adam_b2);
+        return;
+    }
     const int d = f.d;
     const long ostride = (long)d * d + d;
     GemmArgs g{};  // C[o, k] = sum_j Wo[o, j] Wv[j, k]
@@ -1341,23 +1485,19 @@ static void refresh_folded(tvc_sac* h, hipStream_t st) {
     g.M = d; g.N = d; g.K = d; g.K1 = d; g.lda = d; g.ldb = d; g.ldc = d;
     g.gA = f.layer_stride; g.gB = f.layer_stride; g.gC = ostride;
     launch_gemm(true, false, g, f.layers, st);
-    GemmArgs b{};  // b_ov[o] = sum_j b_v[j] Wo[o, j] + b_o[o]   (1 x d row)
-    b.A = h->P_actor() + f.v_b; b.B = h->P_actor() + f.o_w; b.C = h->ov + (long)d * d;
-    b.M = 1; b.N = d; b.K = d; b.K1 = d; b.lda = d; b.ldb = d; b.ldc = d;
-    b.bias = h->P_actor() + f.o_b;
-    b.gA = f.layer_stride; b.gB = f.layer_stride; b.gC = ostride; b.gBias = f.layer_stride;
-    launch_gemm(true, true, b, f.layers, st);
-    if (f.embed)  // W', b' of the folded embedding, from layer 0's W_ov / b_ov just computed
-        hipLaunchKernelGGL(fold_embed_kernel, dim3(d), dim3(256), 0, st, h->P_actor() + f.e_w,
-                           h->P_actor() + f.e_b, h->cfg.family == 0 ? h->pe : nullptr, h->ov, h->ov + (long)d * d, h->ov + f.e_off,
-                           h->ov + f.e_off + (long)d * f.obs, d, f.obs);
+    const Ticks none{nullptr, 0.f, 0.f, nullptr}, tk{tick, c.adam_b1, c.adam_b2, nullptr};
+    FoldArgs fa{};
+    fa.P = h->P_actor(); fa.OV = h->ov; fa.pe0 = c.family == 0 ? h->pe : nullptr;
+    fa.o_w = f.o_w; fa.o_b = f.o_b; fa.v_b = f.v_b; fa.layer_stride = f.layer_stride; fa.ostride = ostride;
+    fa.embed = f.embed ? 1 : 0; fa.e_w = f.e_w; fa.e_b = f.e_b; fa.e_off = f.e_off; fa.d = d; fa.obs = f.obs;
+    hipLaunchKernelGGL(fold_kernel, dim3(d, f.layers), dim3(256), 0, st, fa, h->rows_ok ? none : tk);
     if (h->rows_ok) {  // re-pack the acting megakernel's weight stream from the fresh parameters / folded weights
-        hipLaunchKernelGGL(pack_actor_kernel, dim3(h->rows_tiles + h->rows_vecs), dim3(256), 0, st, h->P_actor(), h->ov, h->d_ptiles,
-                           h->rows_tiles, h->d_pvecs, reinterpret_cast<float4*>(h->pack), h->pack + (long)h->rows_tiles * 4096);
         const float* P = h->P_actor();
-        hipLaunchKernelGGL(pack_head_kernel, dim3(1), dim3(256), 0, st, P + h->head_off[0], P + h->head_off[1], P + h->head_off[2],
-                           P + h->head_off[3], 2 * h->cfg.act_dim,
-                           h->pack + (long)h->rows_tiles * 4096 + (long)h->cfg.n_layers * AR_LAYER_VEC);
+        HeadPack hp{P + h->head_off[0], P + h->head_off[1], P + h->head_off[2], P + h->head_off[3], 2 * c.act_dim,
+                    h->pack + (long)h->rows_tiles * 4096 + (long)c.n_layers * AR_LAYER_VEC};
+        hipLaunchKernelGGL(pack_actor_kernel, dim3(h->rows_tiles + h->rows_vecs + 1), dim3(256), 0, st, h->P_actor(), h->ov,
+                           h->d_ptiles, h->rows_tiles, h->d_pvecs, h->rows_vecs, reinterpret_cast<float4*>(h->pack),
+                           h->pack + (long)h->rows_tiles * 4096, hp, tk);
     }
 }
 
@@ -1366,7 +1506,7 @@ static void refresh_folded(tvc_sac* h, hipStream_t st) {
 static int set_clocks(tvc_sac* h, const int32_t steps[2]) {
     AdamClock c[2];
     for (int i = 0; i < 2; ++i) {
-        c[i].step = steps[i]; c[i].bc1 = 0.f; c[i].bc2s = 0.f;
+        c[i].step = steps[i]; c[i].pad = 0;
         c[i].b1t = pow((double)h->cfg.adam_b1, (double)steps[i]);
         c[i].b2t = pow((double)h->cfg.adam_b2, (double)steps[i]);
     }
@@ -1376,6 +1516,8 @@ static int set_clocks(tvc_sac* h, const int32_t steps[2]) {
 int tvc_sac_get_adam_steps(tvc_sac* h, int32_t out[2]) {
     if (!h || !out) return tvc::set_error(TVC_EINVAL, "null argument");
     TVC_HIP_CHECK(hipSetDevice(h->device));
+    TVC_HIP_CHECK(hipDeviceSynchronize());
+    flush_tick(h, nullptr);
     AdamClock c[2];
     TVC_HIP_CHECK(hipMemcpy(c, h->clk, sizeof(c), hipMemcpyDeviceToHost));
     out[0] = c[0].step; out[1] = c[1].step;
@@ -1385,6 +1527,8 @@ int tvc_sac_set_adam_steps(tvc_sac* h, const int32_t in[2]) {
     if (!h || !in) return tvc::set_error(TVC_EINVAL, "null argument");
     if (in[0] < 0 || in[1] < 0) return tvc::set_error(TVC_EINVAL, "negative step count");
     TVC_HIP_CHECK(hipSetDevice(h->device));
+    TVC_HIP_CHECK(hipDeviceSynchronize());
+    h->tick_pending = false;
     return set_clocks(h, in);
 }
 
@@ -1418,7 +1562,7 @@ int tvc_sac_snapshot_policy(tvc_sac* h, void* stream) {
 int tvc_sac_sync_derived(tvc_sac* h, void* stream) {
     if (!h) return tvc::set_error(TVC_EINVAL, "null argument");
     TVC_HIP_CHECK(hipSetDevice(h->device));
-    refresh_folded(h, (hipStream_t)stream);
+    refresh_folded(h, (hipStream_t)stream, nullptr);
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1427,11 +1571,9 @@ int tvc_sac_actor_apply(tvc_sac* h, float grad_scale, void* stream) {
     if (!h) return tvc::set_error(TVC_EINVAL, "null argument");
     TVC_HIP_CHECK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    adam_apply(h, h->P_actor(), h->G_actor(), 0, h->n_actor, 1, grad_scale, st);
-    refresh_folded(h, st);
-    const long n = 2 * h->n_critic;
-    hipLaunchKernelGGL(polyak_kernel, dim3((int)std::min<long>((n + 255) / 256, 2048)), dim3(256), 0, st, h->P_tq(), h->P_q(), n,
-                       h->cfg.tau);
+    flush_tick(h, st);
+    adam_apply(h, h->P_actor(), h->G_actor(), 0, h->n_actor, 1, grad_scale, true, st);  // + Polyak of the targets, same launch
+    refresh_folded(h, st, h->clk + 1);                                                   // ... + the actor clock's advance
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1446,11 +1588,18 @@ int tvc_sac_update(tvc_sac* h, const float* s, const float* a, const float* r, c
 
 // Y[M,N] = act(X[M,K] W[N,K]^T + b): the fused Linear kernel on its own (numerics tests and kernel benchmarks).
 // variant: 0 auto, 1 = 64x64 LDS-tiled, 3 = skinny split-K.
+#ifdef TVC_GEMM_STAMPS
+static unsigned long long* g_gemm_stamps = nullptr;
+extern "C" void tvc_debug_set_gemm_stamps(unsigned long long* dev) { g_gemm_stamps = dev; }  // timing build only
+#endif
 int tvc_nn_linear_forward(const float* X, const float* W, const float* b, float* Y, int32_t M, int32_t N, int32_t K, int32_t act,
                           int32_t variant, void* stream) {
     if (!X || !W || !Y || M < 1 || N < 1 || K < 1) return tvc::set_error(TVC_EINVAL, "bad argument");
     GemmArgs g{};
     g.A = X; g.B = W; g.C = Y; g.M = M; g.N = N; g.K = K; g.K1 = K; g.lda = K; g.ldb = K; g.ldc = N; g.bias = b; g.act = act;
+#ifdef TVC_GEMM_STAMPS
+    g.stamps = g_gemm_stamps;
+#endif
     g_force_variant = variant;
     launch_gemm(true, true, g, 1, (hipStream_t)stream);
     g_force_variant = 0;
