@@ -641,7 +641,9 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device,
     else:
         from tvc_ai_amd import _native as nat
         L = nat.load()
-        rows_kernel = args.family == 0 and n >= 12288  # the one-launch row-owner acting kernel (csrc/tvc_actor_rows.h)
+        # the whole acting pass as one launch: from 16 384 rows the row-owner kernel (csrc/tvc_actor_rows.h: 64 rows per workgroup),
+        # from 1 024 rows its split sibling (csrc/tvc_actor_split.h: 16 rows per workgroup, the four waves split every Linear)
+        rows_kernel = args.family == 0 and n >= 1024
         if rows_kernel:
             # dominant kernel of the train loop = the WHOLE acting pass as one launch: every Linear of the policy on
             # v_mfma_f32_16x16x4_f32 (dense f32 peak 157.3 TFLOP/s), activations in registers, weights streamed through LDS.
@@ -654,18 +656,19 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device,
             us = graph_time_us(lambda k: sacr.act(ob, ep, out=outs), 5, device)
             macs = 16 * 256 + 3 * 256 * 256 + 4 * (2 * 256 * 512) + 256 * 512 + 512 * 512 + 512 * 4
             flops = 2.0 * macs * n
-            kname = "tvcnn::actor_rows_kernel (policy forward of all rows in one launch: 4 encoder layers + head + sample)"
+            kshort = "tvcnn::actor_rows_kernel" if n >= 16384 else "tvcnn::actor_split_kernel"
+            kname = kshort + " (policy forward of all rows in one launch: 4 encoder layers + head + sample)"
             import ctypes as C
             clk = (C.c_double * 3)()
             clock = None
-            if L.tvc_debug_rows_clock(sacr._h, ob.data_ptr(), n, 20, clk, torch.cuda.current_stream(device).cuda_stream) == 0:
+            if n >= 16384 and L.tvc_debug_rows_clock(sacr._h, ob.data_ptr(), n, 20, clk, torch.cuda.current_stream(device).cuda_stream) == 0:
                 clock = {"in_kernel_mhz": clk[0], "median_workgroup_lifetime_us": clk[1], "workgroups": int(clk[2]),
                          "f32_mfma_peak_at_that_clock_tflops": clk[0] * 1e6 * 64 * 4 * 256 / 1e12}
-            traffic = pmc_traffic(((n + 63) // 64) * 256, "tvcnn::actor_rows_kernel")
+            traffic = pmc_traffic(((n + 63) // 64) * 256 if n >= 16384 else ((n + 15) // 16) * 256, kshort)
             sacr.close()
             del ob, ep, outs
             tf = flops / (us * 1e-6) / 1e12
-            loop = in_loop_us("tvcnn::actor_rows_kernel", n)
+            loop = in_loop_us(kshort, n)
             rep["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                "frac": tf / MFMA_F32_PEAK_TF, "traffic": traffic,
                                "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc pass, not measured in this run)" if traffic else None,

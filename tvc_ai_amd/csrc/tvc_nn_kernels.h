@@ -959,8 +959,13 @@ __device__ __forceinline__ void skinny_body(const GemmArgs& g, int bx, int by, l
     }
     skinny_epilogue(g, acc, red, m0, n0, z, pre);
 }
+#ifdef TVC_SKINNY_LB4
+#define TVC_SKINNY_BOUNDS __launch_bounds__(256, 4)  // <= 128 VGPRs: two workgroups fit into the half of a CU the acting kernel leaves
+#else
+#define TVC_SKINNY_BOUNDS __launch_bounds__(256)
+#endif
 template <bool A_KC, bool B_KC, bool FAST>
-__global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g) {
+__global__ void TVC_SKINNY_BOUNDS gemm_skinny_kernel(GemmArgs g) {
     warm_kernargs<sizeof(GemmArgs)>();
     TVC_LEARNER_PRIO();
     __shared__ float red[4][32 * 33];
@@ -1023,7 +1028,10 @@ __global__ void __launch_bounds__(256) gemm_skinny_ln_kernel(GemmArgs g) {
             bq[pass][u] = *reinterpret_cast<const float4*>(bet + (s_begin + u) * 16 + kq);
         }
     }
-    const bool writer = bx == 0;  // column tile 0 writes the norm's side outputs
+    const bool writer = bx == 0;  // column tile 0 writes the rows' statistics
+    // the materialised output is written by ALL column tiles, each one its share of the k-steps (k-step s by tile s mod gridDim.x):
+    // one tile writing its 32 complete rows alone was 32 KB of stores through one CU, the slowest workgroup of the launch
+    const int ngx = gridDim.x;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1 && !two) break;
@@ -1081,7 +1089,7 @@ __global__ void __launch_bounds__(256) gemm_skinny_ln_kernel(GemmArgs g) {
                     if (last && g.lnDrop.ctr) v *= drop_factor(g.lnDrop, key, row, k0 + j);
                     a[u][i][j] = v;
                 }
-                if (writer && yo)
+                if (yo && ((s_begin + u) % ngx) == bx % ngx)
                     *reinterpret_cast<float4*>(yo + z * ln.gY + (long)row * K + k0) = make_float4(a[u][i][0], a[u][i][1], a[u][i][2], a[u][i][3]);
             }
         }
@@ -1116,7 +1124,7 @@ struct GemmPair {
     int nw, w_tiles_x, x_tiles_x;
 };
 template <bool FAST>
-__global__ void __launch_bounds__(256) gemm_skinny_bwd_kernel(GemmPair p) {
+__global__ void TVC_SKINNY_BOUNDS gemm_skinny_bwd_kernel(GemmPair p) {
     warm_kernargs<sizeof(GemmPair)>();
     TVC_LEARNER_PRIO();
     __shared__ float red[4][32 * 33];

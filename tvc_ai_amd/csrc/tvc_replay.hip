@@ -42,7 +42,7 @@ __device__ __forceinline__ bool last_arrival(unsigned* cnt) {
 __global__ void replay_insert_kernel(float* __restrict__ buf, long cap, long* __restrict__ st, const float* __restrict__ s,
                                      const float* __restrict__ a, const float* __restrict__ r, const float* __restrict__ s2,
                                      const unsigned char* __restrict__ term, const unsigned char* __restrict__ trunc, int n,
-                                     int no, int na) {
+                                     int no, int na, int fused_advance) {
     const int W = 2 * no + na + 2;
     const long head = st[0], size = st[1];
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)n * W; i += (long)gridDim.x * blockDim.x) {
@@ -55,10 +55,14 @@ __global__ void replay_insert_kernel(float* __restrict__ buf, long cap, long* __
         else v = (term[row] | (trunc ? trunc[row] : 0)) ? 1.0f : 0.0f;  // done = terminated or truncated (scripts/train.py:582)
         buf[((head + row) % cap) * W + c] = v;
     }
-    if (last_arrival(reinterpret_cast<unsigned*>(st + 4)) && threadIdx.x == 0) {
+    if (fused_advance && last_arrival(reinterpret_cast<unsigned*>(st + 4)) && threadIdx.x == 0) {
         st[0] = (head + n) % cap;
         st[1] = size + n > cap ? cap : size + n;
     }
+}
+__global__ void replay_advance_kernel(long* st, long cap, int n) {
+    st[0] = (st[0] + n) % cap;
+    st[1] = st[1] + n > cap ? cap : st[1] + n;
 }
 
 __global__ void replay_sample_kernel(const float* __restrict__ buf, long* __restrict__ st, unsigned seed_lo,
@@ -149,8 +153,13 @@ int tvc_replay_insert(tvc_replay* rb, const float* s, const float* a, const floa
     TVC_HIP_CHECK(hipSetDevice(rb->device));
     const int W = 2 * rb->no + rb->na + 2;
     const long total = (long)n * W;
-    hipLaunchKernelGGL(replay_insert_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 256)), dim3(256), 0,
-                       (hipStream_t)stream, rb->buf, rb->cap, rb->st, s, a, r, s2, term, trunc, n, rb->no, rb->na);
+    // up to 512 workgroups the counters advance inside this launch (last workgroup to arrive); a larger insert keeps one element
+    // per thread and a second, one-thread launch: thousands of arrivals on one address would cost more than the launch they save
+    const long blocks = (total + 255) / 256;
+    const int fused = blocks <= 512 ? 1 : 0;
+    hipLaunchKernelGGL(replay_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rb->buf, rb->cap, rb->st, s, a,
+                       r, s2, term, trunc, n, rb->no, rb->na, fused);
+    if (!fused) hipLaunchKernelGGL(replay_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rb->st, rb->cap, (int)n);
     TVC_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -20,6 +20,7 @@
 #include "tvc_common.h"
 #include "tvc_nn_kernels.h"
 #include "tvc_actor_rows.h"
+#include "tvc_actor_split.h"
 
 using namespace tvcnn;
 
@@ -283,8 +284,12 @@ static void launch_gemm_ln(const GemmArgs& g, int G, hipStream_t st) {
     if (g.K == 256) hipLaunchKernelGGL((gemm_skinny_ln_kernel<4>), grid, block, 0, st, g);
     else hipLaunchKernelGGL((gemm_skinny_ln_kernel<8>), grid, block, 0, st, g);
 }
-static int fold_ln_enabled() {  // TVC_FOLD_LN=0: LayerNorms of the update run as their own launches again (A/B timing)
-    static const int v = [] { const char* e = getenv("TVC_FOLD_LN"); return e ? atoi(e) : 1; }();
+// TVC_FOLD_LN=1 computes the update's LayerNorms inside the consumer GEMM's operand load (13 launches fewer, 92 -> 79).  OFF by
+// default: measured SLOWER, 559 vs 535 us per update alone and 0.74 vs 0.71 ms per step at 4 096 envs (profiles/r03_c_update.md):
+// a LayerNorm launch is cheap (4 KB of rows per workgroup), while the folded GEMM cannot start its MFMAs before all of its rows
+// have arrived and been reduced, and its 186 - 256 VGPRs keep it from running beside the acting kernel.
+static int fold_ln_enabled() {
+    static const int v = [] { const char* e = getenv("TVC_FOLD_LN"); return e ? atoi(e) : 0; }();
     return v;
 }
 
@@ -898,6 +903,7 @@ struct tvc_sac {
     bool tick_pending = false;                    // the critics' Adam clock is one step behind: its advance rides on the next
                                                   // launch of the chain (tvc_sac_actor_grads), or is flushed by whoever needs it
     bool lds_attr_set = false;                    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this handle's device
+    bool split_attr_set = false;                  // ... for actor_split_kernel
     unsigned long long* rows_stamps = nullptr;    // diagnostics: set by rows_probe around its launches
     float* P_actor() { return params; }
     float* P_q() { return params + n_actor; }
@@ -912,8 +918,12 @@ static bool rows_supported(const tvc_sac_cfg& c, const FoldInfo& f) {
     return c.family == 0 && f.embed && c.d_model == 256 && c.ff_dim == 512 && c.head1 == 512 && c.head2 == 512 &&
            2 * c.act_dim <= 4 && c.obs_dim <= 16 && f.layers == c.n_layers && c.pe_rows == 1;
 }
-static int rows_min_rows() {  // acting batches at least this large take the one-launch path (64 rows per workgroup)
-    static const int v = [] { const char* e = getenv("TVC_ROWS_MIN"); return e ? atoi(e) : 12288; }();
+static int rows_min_rows() {  // acting batches at least this large take the one-launch path with 64 rows per workgroup
+    static const int v = [] { const char* e = getenv("TVC_ROWS_MIN"); return e ? atoi(e) : 16384; }();
+    return v;
+}
+static int split_min_rows() {  // ... and from here up to rows_min_rows() the one-launch path with 16 rows per workgroup (tvc_actor_split.h)
+    static const int v = [] { const char* e = getenv("TVC_SPLIT_MIN"); return e ? atoi(e) : 1024; }();
     return v;
 }
 // Descriptor tables of pack_actor_kernel: the tile stream in the order actor_rows_kernel consumes it, and the vector section.
@@ -1261,6 +1271,27 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
             dyn_lds = 65536;
         }
         hipLaunchKernelGGL(actor_rows_kernel, dim3((n + 63) / 64), dim3(256), dyn_lds, st, a);
+        TVC_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    if (h->rows_ok && !h->cfg.use_se && n >= split_min_rows() && g_force_variant == 0) {
+        // the whole pass as one launch, 16 rows per workgroup, the four waves splitting every Linear (tvc_actor_split.h)
+        const float* pk = snap ? h->snap_pack : h->pack;
+        ActRowsArgs a{};
+        a.obs = obs; a.eps = eps; a.act = act; a.mean = mean; a.logstd = logstd;
+        a.tiles = reinterpret_cast<const float4*>(pk); a.vec = pk + (long)h->rows_tiles * 4096;
+        a.M = n; a.obs_dim = h->cfg.obs_dim; a.A = A; a.clamp_act = (flags & 1) ? 0 : 1;
+        a.n_layers = h->cfg.n_layers; a.n_tiles = h->rows_tiles; a.stamps = nullptr; a.use_se = 0;
+        size_t dyn_lds = 0;
+        if (flags & 4) {  // "share the CUs": 32 KB of unused dynamic LDS -> one workgroup (4 waves) per CU instead of two
+            if (!h->split_attr_set) {
+                TVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(actor_split_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
+                h->split_attr_set = true;
+            }
+            dyn_lds = 32768;
+        }
+        hipLaunchKernelGGL(actor_split_kernel, dim3((n + 15) / 16), dim3(256), dyn_lds, st, a);
         TVC_HIP_CHECK(hipGetLastError());
         return 0;
     }

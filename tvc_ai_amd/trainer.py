@@ -391,35 +391,39 @@ class VecTrainer:
 
     def uses_rows_kernel(self) -> bool:
         """does the acting pass of this trainer go through the one-launch kernels (whose CU-sharing form the split chooses)?"""
-        return int(self.sac.cfg.family) == 0 and self.n >= 12288 and not self.acting_dropout
+        return int(self.sac.cfg.family) == 0 and self.n >= 1024 and not self.acting_dropout
 
-    def tune_share_rows(self, candidates=None, steps: int = 6):
+    def tune_share_rows(self, candidates=None, steps: int = 20):
         """Choose how many rows the acting kernel handles in its CU-sharing form (the rest run in the exclusive form) from MEASURED
-        step times: each candidate split runs `steps` real train steps (2 more to settle) between HIP events on the main stream with
-        the join inside, the time is maximised over the ranks of a data-parallel job (so it includes the collectives, and every rank
-        picks the same split), and the fastest wins.  Also records the update's end-of-stream slack at the chosen split: how long
-        before the end of the step's main-stream work the learner's stream went idle (negative: the update is the critical path)."""
+        step times: each candidate split runs `steps` real train steps (3 more to settle) in the regime the loop runs in (join
+        deferred to the next step), timed with HIP events around the whole run; the time is maximised over the ranks of a
+        data-parallel job (so it includes the collectives, and every rank picks the same split); the fastest wins.  Also records
+        the update's end-of-stream slack at the chosen split: how long before the end of the step's main-stream work the learner's
+        stream went idle (negative: the update is the critical path)."""
         n = self.n
         if not (self.share_cus and self.overlap) or self.hier is not None:
             return None
         if candidates is None:
-            q = max(64, (n // 8) // 64 * 64)
-            candidates = sorted({0, *[min(n, k * q) for k in range(1, 8)], n})
+            if n >= 16384:  # 64-row workgroups: the split decides how many rows run one workgroup per CU
+                candidates = sorted({(n * k // 8) // 64 * 64 for k in (0, 2, 3, 4, 5, 6, 8)})
+            else:           # 16-row workgroups: all rows at one workgroup per CU, or none
+                candidates = [0, n]
         while self.steps < 2:
             self.step(True)
         results = []
         dj = self.defer_join
-        self.defer_join = False
+        self.defer_join = True
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         try:
             for k in candidates:
                 self.share_rows = int(k)
-                for _ in range(2):
+                for _ in range(3):
                     self.step(True)
                 torch.cuda.synchronize(self.device)
                 e0.record()
                 for _ in range(steps):
                     self.step(True)
+                torch.cuda.current_stream(self.device).wait_stream(self._side)
                 e1.record()
                 torch.cuda.synchronize(self.device)
                 us = e0.elapsed_time(e1) * 1e3 / steps
@@ -434,9 +438,8 @@ class VecTrainer:
             # slack of the learner's stream at the chosen split
             self._side_done = torch.cuda.Event(enable_timing=True)
             m_end = torch.cuda.Event(enable_timing=True)
-            self.defer_join = True
             slacks = []
-            for _ in range(4):
+            for _ in range(5):
                 self.step(True)
                 m_end.record()
                 torch.cuda.synchronize(self.device)
@@ -447,7 +450,7 @@ class VecTrainer:
         self.share_tuning = {"chosen_share_rows": best[0], "us_per_step": best[1],
                              "candidates": [{"share_rows": k, "us_per_step": us} for k, us in results],
                              "update_end_slack_us": sorted(slacks)[len(slacks) // 2],
-                             "note": "slack = main-stream end minus learner-stream end of a step (median of 4), measured after the "
+                             "note": "slack = main-stream end minus learner-stream end of a step (median of 5), measured after the "
                                      "choice; times are max over ranks"}
         return self.share_tuning
 
