@@ -264,3 +264,56 @@ def test_episode_statistics_survive_reset_and_resume(tmp_path):
     assert abs(ea["return_sum"] - eb["return_sum"]) <= 1e-2 * max(1.0, abs(ea["return_sum"]))
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("n", [2048 + 37, 20000])
+def test_train_mode_acting_in_one_launch_matches_the_restatement_mask_for_mask(n):
+    """the reference's get_action runs the policy in TRAIN mode (agent/multi_algorithm_agent.py:765): attention
+    not folded (the attention-weight dropout sits between v_proj and out_proj), dropout1 / FFN dropout / dropout2 and the two head
+    Dropouts live.  From 1 024 rows NativeSAC.act(train_mode=True) is ONE launch (actor_split_kernel<true>); against the eager
+    restatement with the kernels' own hash masks (DropMasks, site base 300, counter = acting calls so far) element for element,
+    on live parameters and on the snapshot, in the exclusive and in the CU-sharing form."""
+    import importlib.util, json, os
+    from tvc_ai_amd.agent import NativeSAC, sac_cfg
+    torch.set_num_threads(8)
+    p = 0.1
+    sac = NativeSAC(sac_cfg(0, batch_size=64, max_act_rows=32768, dropout_p=p), seed=23)
+    _randomise_vectors(sac, 9)
+    P = sac.export_reference_state("policy")
+    g = torch.Generator().manual_seed(n)
+    obs = torch.randn(n, 10, generator=g) * 0.5
+    eps = torch.randn(n, 2, generator=g)
+    og, eg = obs.cuda(), eps.cuda()
+    masks = st.DropMasks(p, seed=int(sac.cfg.dropout_seed))
+    pick = torch.cat([torch.arange(0, 64), torch.randint(0, n, (400,), generator=g), torch.arange(n - 64, n)])
+    worst = 0.0
+    sac.snapshot_policy()
+    outs = []
+    for call, kw in enumerate((dict(), dict(snapshot=True), dict(snapshot=True, share_cus=True))):
+        act, mean, ls = sac.act(og, eg, train_mode=True, **kw)
+        assert sac.act_counter() == call + 1
+        # the masks are keyed by the row index inside the call: evaluate the restatement on whole leading blocks, compare the picks
+        with torch.no_grad():
+            m_ref, ls_ref = st.actor_forward(P, obs, False, drop=masks.hook(call, 300))
+        a_ref = torch.clamp(m_ref + torch.exp(ls_ref) * eps, -1, 1)
+        for got, want in ((mean, m_ref), (ls, ls_ref), (act, a_ref)):
+            err = (got.cpu()[pick] - want[pick]).abs().max().item()
+            worst = max(worst, err)
+            assert err <= 3e-4 * max(1.0, want.abs().max().item()), (call, kw, err)
+        outs.append(mean.cpu().clone())
+    assert (outs[0] - outs[1]).abs().max().item() > 1e-3  # fresh masks every call
+    _, mean_eval, _ = sac.act(og, eg)  # the deterministic net is a different function of the same weights
+    assert (outs[0] - mean_eval.cpu()).abs().max().item() > 1e-3
+    parity_log.record(f"train_mode_acting_one_launch_n{n}", rows=n, calls=3, worst_abs_err=worst)
+    sac.close()
+
+
+def test_vec_trainer_acts_in_train_mode_when_asked():
+    from tvc_ai_amd.trainer import VecTrainer
+    tr = VecTrainer(4096, family=0, batch_size=256, replay_capacity=200_000, seed=6, overlap=True, acting_dropout=True)
+    assert tr.acting_dropout
+    for _ in range(5):
+        tr.step(True)
+    torch.cuda.synchronize()
+    assert tr.sac.act_counter() == 5 and torch.isfinite(tr.sac.params).all() and tr.act.abs().max().item() <= 1.0
+    tr.close()

@@ -45,6 +45,9 @@ struct ActRowsArgs {
     int M, obs_dim, A, clamp_act, n_layers, n_tiles;
     int use_se;                  // SqueezeExcitation(256, reduction 16) between feature_norm and the head (agent/...:104-118, 206-209)
     unsigned long long* stamps;  // diagnostics (tvc_debug_rows_clock): per workgroup {s_memtime, s_memrealtime} at start and end, XCC_ID, HW_ID
+    // train-mode acting (actor_split_kernel<true> only): second vector section (b_e, per layer b_v / b_o, beta6 x W8, b8), PE(0),
+    // and the dropout hash parameters (tvc_nn_kernels.h: DropArgs)
+    const float* tvec; const float* pe0; const int* drop_ctr; unsigned drop_thresh, drop_seed; float drop_scale;
 };
 
 #ifdef AR_TRACE
@@ -401,7 +404,9 @@ struct PackVec { long src; int dst, count, from_ov; };
 // fold that do not depend on the input are made by the LAST workgroup of pack_actor_kernel, once per policy update, into the
 // vector tail:
 //   +3584  gW[o][n] = gamma6[n] W8[o][n]   (o < 2A, else 0)      +5632  E[o] = sum_n beta6[n] W8[o][n] + b8[o]      +5636  G[o] = sum_n gW[o][n]
-struct HeadPack { const float* gamma6; const float* beta6; const float* W8; const float* b8; int n_out; float* tail; };
+struct HeadPack { const float* gamma6; const float* beta6; const float* W8; const float* b8; int n_out; float* tail;
+                  float* tail_t; };  // tail_t (train-mode stream, may be null): bW[o][n] = beta6[n] W8[o][n] at +512 o, b8[o] at +2048
+struct PackSet { const PackTile* tiles; int n_tiles; const PackVec* vecs; int n_vecs; float4* out_tiles; float* out_vec; };
 __device__ __forceinline__ void pack_head(const HeadPack& hp, float (*red)[4][256]) {
     const int tid = threadIdx.x;
     for (int o = 0; o < 4; ++o) {
@@ -410,6 +415,7 @@ __device__ __forceinline__ void pack_head(const HeadPack& hp, float (*red)[4][25
             const float w = o < hp.n_out ? hp.W8[o * 512 + n] : 0.0f;
             const float gw = hp.gamma6[n] * w;
             hp.tail[3584 + 512 * o + n] = gw;
+            if (hp.tail_t) hp.tail_t[512 * o + n] = hp.beta6[n] * w;
             g += gw;
             e = fmaf(hp.beta6[n], w, e);
         }
@@ -422,19 +428,28 @@ __device__ __forceinline__ void pack_head(const HeadPack& hp, float (*red)[4][25
         for (int i = 0; i < 256; ++i) s += red[which][o][i];
         if (which == 0) hp.tail[5636 + o] = s;
         else hp.tail[5632 + o] = s + (o < hp.n_out ? hp.b8[o] : 0.0f);
+        if (which == 1 && hp.tail_t) hp.tail_t[2048 + o] = o < hp.n_out ? hp.b8[o] : 0.0f;
     }
 }
-__global__ void __launch_bounds__(256) pack_actor_kernel(const float* __restrict__ P, const float* __restrict__ OV,
-                                                         const PackTile* __restrict__ tiles, int n_tiles,
-                                                         const PackVec* __restrict__ vecs, int n_vecs, float4* __restrict__ out_tiles,
-                                                         float* __restrict__ out_vec, HeadPack hp, Ticks tk) {
+// two streams per launch: the acting net (attention and embedding folded) and, when train-mode acting is available, the net as trained
+__global__ void __launch_bounds__(256) pack_actor_kernel(const float* __restrict__ P, const float* __restrict__ OV, PackSet s0, PackSet s1,
+                                                         HeadPack hp, Ticks tk) {
     __shared__ float red[2][4][256];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (b == n_tiles + n_vecs) {  // last workgroup: the folded output head (+ the riders of this launch)
+    int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n0 = s0.n_tiles + s0.n_vecs, n1 = s1.n_tiles + s1.n_vecs;
+    if (b == n0 + n1) {  // last workgroup: the folded output head (+ the riders of this launch)
         if (tid == 0) run_ticks(tk);
         pack_head(hp, red);
         return;
     }
+    const bool second = b >= n0;
+    if (second) b -= n0;
+    const PackTile* __restrict__ tiles = second ? s1.tiles : s0.tiles;
+    const PackVec* __restrict__ vecs = second ? s1.vecs : s0.vecs;
+    const int n_tiles = second ? s1.n_tiles : s0.n_tiles;
+    float4* __restrict__ out_tiles = second ? s1.out_tiles : s0.out_tiles;
+    float* __restrict__ out_vec = second ? s1.out_vec : s0.out_vec;
     if (b < n_tiles) {
         const PackTile t = tiles[b];
         const float* base = (t.from_ov ? OV : P) + t.src;

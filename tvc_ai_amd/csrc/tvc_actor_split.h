@@ -129,6 +129,33 @@ __device__ __forceinline__ void as_rowsum(float* red, float (&v)[NV], int wave, 
     for (int k = 0; k < NV; ++k) v[k] = red[(k * 4 + 0) * 16 + l15] + red[(k * 4 + 1) * 16 + l15] + red[(k * 4 + 2) * 16 + l15] + red[(k * 4 + 3) * 16 + l15];
 }
 
+// Train-mode acting (TRAIN instantiation): the reference's get_action runs the policy with Dropout(0.1) live (no .eval() anywhere,
+// agent/multi_algorithm_agent.py:765).  The masks are the counter hash of tvc_nn_kernels.h (drop_key / drop_factor: keyed by the
+// acting-call counter, the site = 300 + op index of the training net, the handle's seed, row and column), so the per-layer path,
+// this kernel and oracle/sac_torch.py: DropMasks agree element for element.
+struct AsDrop {
+    unsigned ctr, seed, thresh, rowmix;
+    float scale;
+    __device__ __forceinline__ unsigned key(int op) const {
+        return drop_mix(ctr ^ ((300u + (unsigned)op) * 0x9E3779B9u) ^ seed);  // (z = 0: one parameter group)
+    }
+    // keep / drop factor of mask element c (= column / group) of this lane's row
+    __device__ __forceinline__ float f(unsigned key, unsigned c) const {
+        const unsigned x = drop_mix(key ^ rowmix ^ ((c >> 1) * 0x9E3779B1u));
+        const unsigned b = (c & 1u) ? (x >> 16) : (x & 0xFFFFu);
+        return b >= thresh ? scale : 0.0f;
+    }
+    // elementwise mask on tile t of a row (features 16 t + 4 q + r)
+    __device__ __forceinline__ void tile(unsigned key, int t, int q, f32x4& v) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] *= f(key, (unsigned)(16 * t + 4 * q + r));
+    }
+};
+
+// TRAIN = false: the deterministic net with the attention and the embedding folded (W_ov, W'): stream of rows_tables().
+// TRAIN = true : the net as trained -- embedding, then per layer v_proj, head-granular attention-weight dropout, out_proj,
+//                dropout1, FFN with its dropout, dropout2, and the two head dropouts: stream of rows_tables_train().
+template <bool TRAIN>
 __global__ void __launch_bounds__(256, 2) actor_split_kernel(ActRowsArgs a) {
     __shared__ __attribute__((aligned(16))) float4 xb[AS_XBUF_F4];
     float* red = reinterpret_cast<float*>(xb);  // (the small per-row reductions reuse the head of the buffer, between barriers)
@@ -141,6 +168,12 @@ __global__ void __launch_bounds__(256, 2) actor_split_kernel(ActRowsArgs a) {
     // outputs) and inside one half of a deep tile image[a][q][n < 128]
     const unsigned lb = (unsigned)(q * 256 + l15) * 16u, lbd = (unsigned)(q * 128 + l15) * 16u;
 
+    AsDrop dr{};
+    const float* __restrict__ tvec = a.tvec;
+    if (TRAIN) {
+        dr.ctr = (unsigned)*a.drop_ctr; dr.seed = a.drop_seed; dr.thresh = a.drop_thresh; dr.scale = a.drop_scale;
+        dr.rowmix = drop_mix((unsigned)row + 0x632BE5ABu);
+    }
     // observation as the first B operand: x[m][k = 4 q + r], zero beyond obs_dim (clamped address, selected after the load)
     f32x4 xin;
 #pragma unroll
@@ -150,9 +183,9 @@ __global__ void __launch_bounds__(256, 2) actor_split_kernel(ActRowsArgs a) {
         xin[r] = k < a.obs_dim ? v : 0.0f;
     }
     f32x4 x[16];
-    int t0 = 0;  // index of the next tile of the packed stream (order: rows_tables() in tvc_sac.hip)
-    // ---- layer 0, first sublayer: embedding + PE(0) + folded attention + residual as ONE obs -> 256 Linear, then norm1
-    {
+    int t0 = 0;  // index of the next tile of the packed stream (order: rows_tables() / rows_tables_train() in tvc_sac.hip)
+    if (!TRAIN) {
+        // ---- layer 0, first sublayer: embedding + PE(0) + folded attention + residual as ONE obs -> 256 Linear, then norm1
         f32x4 o[4];
         ar_zero<4>(o);
         as_pass<1, 4, false>(tiles + (long)t0 * AR_TILE_F4, lb + 1024u * wave, &xin, o);
@@ -161,10 +194,46 @@ __global__ void __launch_bounds__(256, 2) actor_split_kernel(ActRowsArgs a) {
         as_allgather16(xb, o, x, wave, lane);
         ar_layernorm<16>(x, vec + 256, vec + 512, q);
         t0 += 2;  // (the stream carries an all-zero second tile behind W', tvc_actor_rows.h)
+    } else {
+        // ---- x = W_e obs + b_e + PE(0)   (agent/...:196-203)
+        f32x4 o[4];
+        ar_zero<4>(o);
+        as_pass<1, 4, false>(tiles + (long)t0 * AR_TILE_F4, lb + 1024u * wave, &xin, o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += ar_vec4(tvec, 4 * wave + j, q) + ar_vec4(a.pe0, 4 * wave + j, q);
+        as_allgather16(xb, o, x, wave, lane);
+        t0 += 1;
     }
     for (int l = 0; l < a.n_layers; ++l) {
         const float* lv = vec + l * AR_LAYER_VEC;
-        if (l > 0) {  // x = norm1(x + W_ov x + b_ov): output-split, then gathered
+        if (TRAIN) {
+            // self-attention at sequence length 1 = out_proj(dropout_heads(v_proj(x))): softmax over one key is 1, so the
+            // attention-weight dropout zeroes / rescales whole heads of V (32 columns each); then dropout1, residual, norm1
+            const float* tl = tvec + 256 + 512 * l;
+            const unsigned kv = dr.key(1 + 6 * l), ko = dr.key(2 + 6 * l);
+            f32x4 o[4];
+            ar_zero<4>(o);
+            as_pass<16, 4, false>(tiles + (long)t0 * AR_TILE_F4, lb + 1024u * wave, x, o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float hm = dr.f(kv, (unsigned)((4 * wave + j) >> 1));  // head = column / 32 = tile / 2
+                o[j] = (o[j] + ar_vec4(tl, 4 * wave + j, q)) * hm;
+            }
+            f32x4 v[16];
+            as_allgather16(xb, o, v, wave, lane);
+            ar_zero<4>(o);
+            as_pass<16, 4, false>(tiles + (long)(t0 + 16) * AR_TILE_F4, lb + 1024u * wave, v, o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] += ar_vec4(tl + 256, 4 * wave + j, q);
+                dr.tile(ko, 4 * wave + j, q, o[j]);
+            }
+            as_allgather16(xb, o, v, wave, lane);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) x[t] += v[t];
+            ar_layernorm<16>(x, lv + 256, lv + 512, q);
+            t0 += 32;
+        } else if (l > 0) {  // x = norm1(x + W_ov x + b_ov): output-split, then gathered
             f32x4 o[4];
             ar_zero<4>(o);
             as_pass<16, 4, false>(tiles + (long)t0 * AR_TILE_F4, lb + 1024u * wave, x, o);
@@ -187,14 +256,20 @@ __global__ void __launch_bounds__(256, 2) actor_split_kernel(ActRowsArgs a) {
             const f32x4 b4 = ar_vec4(lv + 768 + 128 * wave, t, q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[t][r] = gelu_f(h[t][r] + b4[r]);
+            if (TRAIN) dr.tile(dr.key(4 + 6 * l), 8 * wave + t, q, h[t]);  // the FFN's dropout (hidden units 128 w + ...)
         }
         f32x4 part[16];
         ar_zero<16>(part);
         as_pass<8, 16, false>(tiles + (long)(t0 + 16 * wave + 8) * AR_TILE_F4, lb, h, part);
         f32x4 y[16];
         as_reduce16(xb, part, y, wave, lane);
+        const unsigned k2 = TRAIN ? dr.key(5 + 6 * l) : 0u;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) x[t] += y[t] + ar_vec4(lv + 1280, t, q);
+        for (int t = 0; t < 16; ++t) {
+            y[t] += ar_vec4(lv + 1280, t, q);
+            if (TRAIN) dr.tile(k2, t, q, y[t]);  // dropout2
+            x[t] += y[t];
+        }
         ar_layernorm<16>(x, lv + 1536, lv + 1792, q);
         t0 += 64;
     }
@@ -229,12 +304,19 @@ __global__ void __launch_bounds__(256, 2) actor_split_kernel(ActRowsArgs a) {
             const f32x4 g4 = ar_vec4(tv + 1024 + 128 * wave, t, q), b4 = ar_vec4(tv + 1536 + 128 * wave, t, q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) pp[t][r] = (pp[t][r] - mean) * rstd * g4[r] + b4[r];
+            if (TRAIN) dr.tile(dr.key(3 + 6 * a.n_layers), 8 * wave + t, q, pp[t]);  // Dropout behind policy_head.2
         }
     }
     // ---- 512 -> 512 GELU LayerNorm -> 2A outputs, input-split over the wave's own 128 features, in two halves of 256 outputs; the
     // LayerNorm and the output Linear are folded into running sums (actor_rows_kernel): of each half's total, this wave finishes
     // the 64 outputs 64 w .. 64 w + 63
-    float s1 = 0.0f, s2 = 0.0f, d[4] = {0.f, 0.f, 0.f, 0.f};
+    // TRAIN: Dropout behind policy_head.6 sits between the folded LayerNorm and the output Linear,
+    //   out[o] = sum_n m_n (rstd (g_n - mean) gamma_n + beta_n) W8[o, n] + b8[o]
+    //          = rstd (sum_n m_n g_n gW[o][n] - mean sum_n m_n gW[o][n]) + sum_n m_n bW[o][n] + b8[o],
+    // so the two "input-independent" sums of pack_head become per-row sums over the kept columns (gm, em below)
+    float s1 = 0.0f, s2 = 0.0f, d[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {0.f, 0.f, 0.f, 0.f}, em[4] = {0.f, 0.f, 0.f, 0.f};
+    const unsigned k6 = TRAIN ? dr.key(5 + 6 * a.n_layers) : 0u;
+    const float* bw = TRAIN ? tvec + 256 + 512 * a.n_layers : nullptr;  // bW[o][n] = beta6[n] W8[o][n], then b8[4]
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         f32x4 part[16];
@@ -254,25 +336,45 @@ __global__ void __launch_bounds__(256, 2) actor_split_kernel(ActRowsArgs a) {
             f32x4 gw[4];
 #pragma unroll
             for (int o = 0; o < 4; ++o) gw[o] = ar_vec4(tv + 3584 + 512 * o, tt, q);
+            f32x4 bwv[4];
+            if (TRAIN) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) bwv[o] = ar_vec4(bw + 512 * o, tt, q);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = gelu_f(s[r] + b4[r]);
                 s1 += v;
                 s2 = fmaf(v, v, s2);
+                const float m = TRAIN ? dr.f(k6, (unsigned)(16 * tt + 4 * q + r)) : 1.0f;
 #pragma unroll
-                for (int o = 0; o < 4; ++o) d[o] = fmaf(v, gw[o][r], d[o]);
+                for (int o = 0; o < 4; ++o) {
+                    d[o] = fmaf(v * m, gw[o][r], d[o]);
+                    if (TRAIN) { gm[o] = fmaf(m, gw[o][r], gm[o]); em[o] = fmaf(m, bwv[o][r], em[o]); }
+                }
             }
         }
     }
-    float fin[6] = {s1, s2, d[0], d[1], d[2], d[3]};
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { fin[k] += __shfl_xor(fin[k], 16); fin[k] += __shfl_xor(fin[k], 32); }
-    as_rowsum<6>(red, fin, wave, l15, q);
-    const float mean = fin[0] * (1.0f / 512.0f);
-    const float rstd = rsqrtf(fmaxf(fin[1] * (1.0f / 512.0f) - mean * mean, 0.0f) + 1e-5f);
     float out[4];
+    if (!TRAIN) {
+        float fin[6] = {s1, s2, d[0], d[1], d[2], d[3]};
 #pragma unroll
-    for (int o = 0; o < 4; ++o) out[o] = rstd * (fin[2 + o] - mean * tv[5636 + o]) + tv[5632 + o];
+        for (int k = 0; k < 6; ++k) { fin[k] += __shfl_xor(fin[k], 16); fin[k] += __shfl_xor(fin[k], 32); }
+        as_rowsum<6>(red, fin, wave, l15, q);
+        const float mean = fin[0] * (1.0f / 512.0f);
+        const float rstd = rsqrtf(fmaxf(fin[1] * (1.0f / 512.0f) - mean * mean, 0.0f) + 1e-5f);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) out[o] = rstd * (fin[2 + o] - mean * tv[5636 + o]) + tv[5632 + o];
+    } else {
+        float fin[14] = {s1, s2, d[0], d[1], d[2], d[3], gm[0], gm[1], gm[2], gm[3], em[0], em[1], em[2], em[3]};
+#pragma unroll
+        for (int k = 0; k < 14; ++k) { fin[k] += __shfl_xor(fin[k], 16); fin[k] += __shfl_xor(fin[k], 32); }
+        as_rowsum<14>(red, fin, wave, l15, q);
+        const float mean = fin[0] * (1.0f / 512.0f);
+        const float rstd = rsqrtf(fmaxf(fin[1] * (1.0f / 512.0f) - mean * mean, 0.0f) + 1e-5f);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) out[o] = rstd * (fin[2 + o] - mean * fin[6 + o]) + fin[10 + o] + bw[2048 + o];
+    }
     // mean, clamped log_std, action = mean + exp(log_std) eps  (agent/...:224-225, 780-782, 789)
     if (wave == 0 && q == 0 && row < a.M) {
         for (int j = 0; j < a.A; ++j) {

@@ -670,6 +670,7 @@ __global__ void concat_kernel(const float* __restrict__ s, const float* __restri
 
 // head output [M,2A] -> mean, clamped log_std, action = mean + exp(log_std) * eps  (agent/...:224-225, 780-782, 964-966)
 __global__ void adam_tick_kernel(AdamClock* clk, float b1, float b2) { adam_clock_advance(clk, b1, b2); }  // (rare: flush paths)
+__global__ void act_ctr_tick_kernel(int* ctr) { *ctr += 1; }
 __global__ void sample_action_kernel(const float* __restrict__ head, const float* __restrict__ eps, float* __restrict__ act,
                                      float* __restrict__ mean_out, float* __restrict__ ls_out, int M, int A, int clamp_act,
                                      Ticks tk) {
@@ -899,11 +900,18 @@ struct tvc_sac {
     float *pack = nullptr, *snap_pack = nullptr;  // [rows_tiles * 4096 tile floats | vector section]
     PackTile* d_ptiles = nullptr;
     PackVec* d_pvecs = nullptr;
+    // ... and the stream of the net AS TRAINED (attention and embedding not folded) for train-mode acting (actor_split_kernel<true>)
+    bool train_rows_ok = false;
+    int trows_tiles = 0, trows_vecs = 0;
+    long tpack_floats = 0;
+    float *tpack = nullptr, *snap_tpack = nullptr;  // [trows_tiles * 4096 tile floats | train vector section]
+    PackTile* d_tptiles = nullptr;
+    PackVec* d_tpvecs = nullptr;
     float* tq = nullptr;                          // [2, B]: output of the target critics (read by q_loss_kernel)
     bool tick_pending = false;                    // the critics' Adam clock is one step behind: its advance rides on the next
                                                   // launch of the chain (tvc_sac_actor_grads), or is flushed by whoever needs it
     bool lds_attr_set = false;                    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) done for this handle's device
-    bool split_attr_set = false;                  // ... for actor_split_kernel
+    bool split_attr_set = false, tsplit_attr_set = false;  // ... for actor_split_kernel<false> / <true>
     unsigned long long* rows_stamps = nullptr;    // diagnostics: set by rows_probe around its launches
     float* P_actor() { return params; }
     float* P_q() { return params + n_actor; }
@@ -982,6 +990,40 @@ static void rows_tables(const tvc_sac_cfg& c, const NetDef& actor, const FoldInf
     for (int half = 0; half < 2; ++half) pass(off("policy_head.4.weight"), 512, 256 * half, 0, 32, 512, 0);
     vec(off("policy_head.4.bias"), tv + 2048, 512, 0);
     // policy_head.6 (LayerNorm) and policy_head.8 (output Linear) enter the tail through pack_head_kernel, already folded
+}
+
+// Train-mode stream: embedding (one tile), then per encoder layer v_proj (16 tiles), out_proj (16), the FFN as in rows_tables(),
+// then the head.  Vector section: +0 b_e, per layer l at 256 + 512 l: b_v, b_o; behind the layers beta6 x W8 [4][512] and b8[4]
+// (pack_head with tail_t).
+static long train_vec_floats(const tvc_sac_cfg& c) { return 256 + 512L * c.n_layers + 4 * 512 + 16; }
+static void rows_tables_train(const tvc_sac_cfg& c, const NetDef& actor, std::vector<PackTile>& tiles, std::vector<PackVec>& vecs) {
+    auto off = [&](const std::string& name) -> long {
+        for (const TensorInfo& t : actor.tensors)
+            if (t.name == name) return t.off;
+        return -1;
+    };
+    const int d = 256;
+    auto pass = [&](long src, int ld, int n0, int k0, int ktiles, int kvalid) {
+        for (int kt = 0; kt < ktiles; ++kt) tiles.push_back(PackTile{src + (long)n0 * ld, ld, k0 + 16 * kt, kvalid, 0, 0});
+    };
+    auto deep = [&](long src, int ld, int n0, int kt2, int kvalid) {
+        for (int kt = 0; kt < kt2; ++kt) tiles.push_back(PackTile{src + (long)n0 * ld, ld, 32 * kt, kvalid, 0, 2});
+    };
+    pass(off("input_embedding.weight"), c.obs_dim, 0, 0, 1, c.obs_dim);
+    vecs.push_back(PackVec{off("input_embedding.bias"), 0, d, 0});
+    for (int l = 0; l < c.n_layers; ++l) {
+        const std::string p = "layers." + std::to_string(l) + ".";
+        pass(off(p + "v_proj.weight"), d, 0, 0, 16, d);
+        pass(off(p + "out_proj.weight"), d, 0, 0, 16, d);
+        for (int quarter = 0; quarter < 4; ++quarter) {
+            deep(off(p + "linear1.weight"), d, 128 * quarter, 8, d);
+            pass(off(p + "linear2.weight"), 512, 0, 128 * quarter, 8, 512);
+        }
+        vecs.push_back(PackVec{off(p + "v_proj.bias"), 256 + 512 * l, d, 0});
+        vecs.push_back(PackVec{off(p + "out_proj.bias"), 512 + 512 * l, d, 0});
+    }
+    for (int half = 0; half < 2; ++half) pass(off("policy_head.0.weight"), d, 256 * half, 0, 16, d);
+    for (int half = 0; half < 2; ++half) pass(off("policy_head.4.weight"), 512, 256 * half, 0, 32, 512);
 }
 
 static long ctx_bytes(const NetDef& nd, int M, int G, bool train) {
@@ -1141,6 +1183,17 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
         h->pack_floats = (long)h->rows_tiles * 4096 + (long)cfg->n_layers * AR_LAYER_VEC + AR_TAIL_VEC + (cfg->use_se ? AR_SE_VEC : 0);
         bytes += 2 * h->pack_floats * 4 + ptiles.size() * sizeof(PackTile) + pvecs.size() * sizeof(PackVec) + 2048;
     }
+    std::vector<PackTile> tptiles;
+    std::vector<PackVec> tpvecs;
+    h->train_rows_ok = h->rows_ok && want_dctx && !cfg->use_se;
+    if (h->train_rows_ok) {
+        rows_tables_train(*cfg, h->actor, tptiles, tpvecs);
+        for (const PackVec& v : tpvecs) h->train_rows_ok = h->train_rows_ok && v.src >= 0;
+        for (const PackTile& t : tptiles) h->train_rows_ok = h->train_rows_ok && t.src >= 0;
+        h->trows_tiles = (int)tptiles.size(); h->trows_vecs = (int)tpvecs.size();
+        h->tpack_floats = (long)h->trows_tiles * 4096 + train_vec_floats(*cfg);
+        bytes += 2 * h->tpack_floats * 4 + tptiles.size() * sizeof(PackTile) + tpvecs.size() * sizeof(PackVec) + 2048;
+    }
     hipError_t he = hipMalloc(&h->slab, bytes);
     if (he != hipSuccess) {
         delete h;
@@ -1178,6 +1231,12 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
         h->d_ptiles = (PackTile*)carve(p, ptiles.size() * sizeof(PackTile));
         h->d_pvecs = (PackVec*)carve(p, pvecs.size() * sizeof(PackVec));
     }
+    if (h->train_rows_ok) {
+        h->tpack = (float*)carve(p, h->tpack_floats * 4);
+        h->snap_tpack = (float*)carve(p, h->tpack_floats * 4);
+        h->d_tptiles = (PackTile*)carve(p, tptiles.size() * sizeof(PackTile));
+        h->d_tpvecs = (PackVec*)carve(p, tpvecs.size() * sizeof(PackVec));
+    }
     if ((long)(p - (char*)h->slab) > bytes) {
         (void)hipFree(h->slab);
         delete h;
@@ -1199,6 +1258,10 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     if (h->rows_ok) {
         he = hipMemcpy(h->d_ptiles, ptiles.data(), ptiles.size() * sizeof(PackTile), hipMemcpyHostToDevice);
         if (he == hipSuccess) he = hipMemcpy(h->d_pvecs, pvecs.data(), pvecs.size() * sizeof(PackVec), hipMemcpyHostToDevice);
+        if (he == hipSuccess && h->train_rows_ok) {
+            he = hipMemcpy(h->d_tptiles, tptiles.data(), tptiles.size() * sizeof(PackTile), hipMemcpyHostToDevice);
+            if (he == hipSuccess) he = hipMemcpy(h->d_tpvecs, tpvecs.data(), tpvecs.size() * sizeof(PackVec), hipMemcpyHostToDevice);
+        }
         if (he != hipSuccess) {
             (void)hipFree(h->slab);
             delete h;
@@ -1239,6 +1302,32 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
         // acting in TRAIN mode, like the reference, which never calls .eval() (agent/...:765): the net as trained (attention not
         // folded -- the attention-weight dropout zeroes whole heads of V) with fresh masks at every dropout site per call
         if (!h->dctx_ok) return tvc::set_error(TVC_EINVAL, "train-mode acting needs family 0 with dropout_p > 0");
+        if (h->train_rows_ok && n >= split_min_rows() && g_force_variant == 0) {
+            // one launch: the split kernel's TRAIN instantiation on the stream of the net as trained (tvc_actor_split.h)
+            const float* pk = snap ? h->snap_pack : h->pack;
+            const float* tpk = snap ? h->snap_tpack : h->tpack;
+            ActRowsArgs a{};
+            a.obs = obs; a.eps = eps; a.act = act; a.mean = mean; a.logstd = logstd;
+            a.tiles = reinterpret_cast<const float4*>(tpk); a.vec = pk + (long)h->rows_tiles * 4096;
+            a.tvec = tpk + (long)h->trows_tiles * 4096; a.pe0 = h->pe;
+            a.M = n; a.obs_dim = h->cfg.obs_dim; a.A = A; a.clamp_act = (flags & 1) ? 0 : 1;
+            a.n_layers = h->cfg.n_layers; a.n_tiles = h->trows_tiles; a.stamps = nullptr; a.use_se = 0;
+            a.drop_ctr = h->act_ctr; a.drop_thresh = (unsigned)lroundf(h->cfg.dropout_p * 65536.0f);
+            a.drop_scale = 65536.0f / (float)(65536u - a.drop_thresh); a.drop_seed = h->cfg.dropout_seed;
+            size_t dyn_lds = 0;
+            if (flags & 4) {
+                if (!h->tsplit_attr_set) {
+                    TVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(actor_split_kernel<true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
+                    h->tsplit_attr_set = true;
+                }
+                dyn_lds = 32768;
+            }
+            hipLaunchKernelGGL(actor_split_kernel<true>, dim3((n + 15) / 16), dim3(256), dyn_lds, st, a);
+            hipLaunchKernelGGL(act_ctr_tick_kernel, dim3(1), dim3(1), 0, st, h->act_ctr);  // every workgroup has read the counter
+            TVC_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
         for (size_t b = 1; b < h->dctx.gY.size(); ++b) h->dctx.gY[b] = (long)n * h->actor.buf_dim[b];
         DropCtl dc;
         dc.ctr = h->act_ctr; dc.thresh = (unsigned)lroundf(h->cfg.dropout_p * 65536.0f);
@@ -1285,13 +1374,13 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
         size_t dyn_lds = 0;
         if (flags & 4) {  // "share the CUs": 32 KB of unused dynamic LDS -> one workgroup (4 waves) per CU instead of two
             if (!h->split_attr_set) {
-                TVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(actor_split_kernel),
+                TVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(actor_split_kernel<false>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 32768));
                 h->split_attr_set = true;
             }
             dyn_lds = 32768;
         }
-        hipLaunchKernelGGL(actor_split_kernel, dim3((n + 15) / 16), dim3(256), dyn_lds, st, a);
+        hipLaunchKernelGGL(actor_split_kernel<false>, dim3((n + 15) / 16), dim3(256), dyn_lds, st, a);
         TVC_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -1525,10 +1614,14 @@ static void refresh_folded(tvc_sac* h, hipStream_t st, AdamClock* tick) {
     if (h->rows_ok) {  // re-pack the acting megakernel's weight stream from the fresh parameters / folded weights
         const float* P = h->P_actor();
         HeadPack hp{P + h->head_off[0], P + h->head_off[1], P + h->head_off[2], P + h->head_off[3], 2 * c.act_dim,
-                    h->pack + (long)h->rows_tiles * 4096 + (long)c.n_layers * AR_LAYER_VEC};
-        hipLaunchKernelGGL(pack_actor_kernel, dim3(h->rows_tiles + h->rows_vecs + 1), dim3(256), 0, st, h->P_actor(), h->ov,
-                           h->d_ptiles, h->rows_tiles, h->d_pvecs, h->rows_vecs, reinterpret_cast<float4*>(h->pack),
-                           h->pack + (long)h->rows_tiles * 4096, hp, tk);
+                    h->pack + (long)h->rows_tiles * 4096 + (long)c.n_layers * AR_LAYER_VEC,
+                    h->train_rows_ok ? h->tpack + (long)h->trows_tiles * 4096 + 256 + 512L * c.n_layers : nullptr};
+        PackSet s0{h->d_ptiles, h->rows_tiles, h->d_pvecs, h->rows_vecs, reinterpret_cast<float4*>(h->pack),
+                   h->pack + (long)h->rows_tiles * 4096};
+        PackSet s1{h->d_tptiles, h->train_rows_ok ? h->trows_tiles : 0, h->d_tpvecs, h->train_rows_ok ? h->trows_vecs : 0,
+                   reinterpret_cast<float4*>(h->tpack), h->train_rows_ok ? h->tpack + (long)h->trows_tiles * 4096 : nullptr};
+        hipLaunchKernelGGL(pack_actor_kernel, dim3(s0.n_tiles + s0.n_vecs + s1.n_tiles + s1.n_vecs + 1), dim3(256), 0, st,
+                           h->P_actor(), h->ov, s0, s1, hp, tk);
     }
 }
 
@@ -1587,6 +1680,8 @@ int tvc_sac_snapshot_policy(tvc_sac* h, void* stream) {
     TVC_HIP_CHECK(hipMemcpyAsync(h->snap_p, h->P_actor(), h->n_actor * sizeof(float), hipMemcpyDeviceToDevice, st));
     TVC_HIP_CHECK(hipMemcpyAsync(h->snap_ov, h->ov, h->ov_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (h->rows_ok) TVC_HIP_CHECK(hipMemcpyAsync(h->snap_pack, h->pack, h->pack_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (h->train_rows_ok)
+        TVC_HIP_CHECK(hipMemcpyAsync(h->snap_tpack, h->tpack, h->tpack_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
 }
 

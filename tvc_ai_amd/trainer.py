@@ -25,7 +25,8 @@ class VecTrainer:
                  replay_capacity: int = 1_000_000, seed: int = 42, rank: int = 0, world: int = 1, updates_per_step: int = 1,
                  max_episode_steps: int = 1000, enable_curiosity: bool = False, overlap: bool = True,
                  enable_hierarchical: bool = False, enable_safety: bool = False, dropout_p: Optional[float] = None,
-                 share_cus: Optional[bool] = None, defer_join: bool = False, share_rows: Optional[int] = None, **env_over):
+                 share_cus: Optional[bool] = None, defer_join: bool = False, share_rows: Optional[int] = None,
+                 acting_dropout: bool = False, **env_over):
         self.device = torch.device(device)
         self.n, self.B, self.world, self.rank = num_envs, batch_size, world, rank
         self.updates_per_step = updates_per_step
@@ -65,7 +66,8 @@ class VecTrainer:
         self._fork = torch.cuda.Event()
         self._side_done = None  # timing event at the end of the learner's stream (tune_share_rows)
         # acting_dropout = True: act in train mode like the reference's get_action (agent/...:765): Dropout live in the policy
-        self.acting_dropout = False
+        # (attention not folded; one launch from 1 024 rows: actor_split_kernel<true>); False = the deterministic folded net
+        self.acting_dropout = bool(acting_dropout) and self.dropout_p > 0.0
         # intrinsic curiosity bonus of the reference's training env (scripts/train.py:318, env/...:496-502)
         self.curiosity = None
         if enable_curiosity:
@@ -391,7 +393,7 @@ class VecTrainer:
 
     def uses_rows_kernel(self) -> bool:
         """does the acting pass of this trainer go through the one-launch kernels (whose CU-sharing form the split chooses)?"""
-        return int(self.sac.cfg.family) == 0 and self.n >= 1024 and not self.acting_dropout
+        return int(self.sac.cfg.family) == 0 and self.n >= 1024
 
     def tune_share_rows(self, candidates=None, steps: int = 20):
         """Choose how many rows the acting kernel handles in its CU-sharing form (the rest run in the exclusive form) from MEASURED
@@ -563,8 +565,8 @@ def bench_train(args, world, rank, device, n_envs=None):
                     share_cus={"auto": None, "on": True, "off": False}[getattr(args, "share_cus", "auto")],
                     defer_join=True,  # the bench synchronises the device around its timed region
                     share_rows=None if int(getattr(args, "share_rows", -1)) < 0 else int(args.share_rows),
+                    acting_dropout=bool(getattr(args, "acting_dropout", False)),
                     enable_hierarchical=shipped, enable_safety=shipped, enable_curiosity=shipped, **env_over)
-    tr.acting_dropout = bool(getattr(args, "acting_dropout", False)) and tr.dropout_p > 0
     if stage is not None:  # the curriculum driver reads device-side episode statistics and owns the stage from here on
         from .curriculum import CurriculumDriver
         from .env import default_curriculum_config
