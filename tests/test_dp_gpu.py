@@ -20,10 +20,18 @@ torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 from tvc_ai_amd.trainer import VecTrainer
 tr = VecTrainer(256, device="cuda:0", family=int(os.environ["TVC_FAMILY"]), batch_size=64, replay_capacity=4096, seed=31 + rank,
-                rank=rank, world=world, overlap=True)
-for _ in range(7):
-    tr.step(True)
+                rank=rank, world=world, overlap=True, defer_join=os.environ.get("TVC_SEGMENTS") == "1")
+if os.environ.get("TVC_SEGMENTS") == "1":   # the launch mode of bench.py at world > 1: segment graphs around the two collectives
+    for _ in range(3):
+        tr.step(True)
+    fn = tr.capture_segments()
+    for _ in range(4):
+        fn()
+else:
+    for _ in range(7):
+        tr.step(True)
 torch.cuda.synchronize()
+assert tr.steps == 7
 p = tr.sac.params.cpu()
 mine = torch.stack([p.sum(), p.abs().sum(), (p * p).sum()]).double()
 both = [torch.zeros_like(mine) for _ in range(world)]
@@ -47,13 +55,13 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("family", [0, 1])
-def test_two_ranks_keep_identical_replicas(family):
+@pytest.mark.parametrize("family,segments", [(0, 0), (1, 0), (0, 1)])
+def test_two_ranks_keep_identical_replicas(family, segments):
     port = _free_port()
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TVC_ROOT=ROOT,
-                   TVC_FAMILY=str(family))
+                   TVC_FAMILY=str(family), TVC_SEGMENTS=str(segments))
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                       text=True))
     outs = []
