@@ -3,7 +3,9 @@
   pmc_run.py gemm 65536 256 256       -> the acting-pass Linear kernel at M N K (tvc_nn_linear_forward)
   pmc_run.py rowln 65536 256 512      -> the fused Linear + residual + LayerNorm kernel (tvc_nn_linear_ln_forward)
   pmc_run.py act 65536                -> the one-launch acting kernel (tvc_sac_act, actor_rows_kernel)
-  pmc_run.py envdr 65536 4194304      -> env_step with full domain randomisation (stage 5) and episode statistics on"""
+  pmc_run.py envdr 65536 4194304      -> env_step with full domain randomisation (stage 5) and episode statistics on
+  pmc_run.py envdr1000 65536          -> the same with the 1000-entry reward history (the train loop's instantiation)
+  pmc_run.py act 4096 8192            -> below 16 384 rows tvc_sac_act launches actor_split_kernel"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -29,11 +31,18 @@ elif mode == "act":
             sac.act(ob, ep, out=outs)
         torch.cuda.synchronize()
         sac.close()
-elif mode == "envdr":
+elif mode in ("envdr", "envdr1000"):  # envdr1000: the train loop's instantiation <W1000, DR> (reference-exact 1000-entry reward history)
     from tvc_ai_amd import VecRocketTVCEnv
     from tvc_ai_amd.env import dr_from_yaml
     for n in [int(x) for x in sys.argv[2:]]:
-        env = VecRocketTVCEnv(n, **dr_from_yaml({}, 5)); env.enable_episode_stats(); env.reset()
+        over = dr_from_yaml({}, 5)
+        if mode == "envdr1000":
+            over["distinct_window"] = 1000
+        env = VecRocketTVCEnv(n, **over); env.enable_episode_stats(); env.reset()
+        if mode == "envdr1000":  # fill every env's 1000-entry history first: the step then scans the whole ring, as in a long run
+            acts0 = (torch.rand((4, n, 2), device="cuda") * 2 - 1).contiguous()
+            for k in range(1010):
+                env.step(acts0[k % 4])
         acts = (torch.rand((4, n, 2), device="cuda") * 2 - 1).contiguous()
         for k in range(40):
             env.step(acts[k % 4])

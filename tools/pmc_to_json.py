@@ -14,7 +14,9 @@ def collect(d, counter):
             if row["Counter_Name"] != counter:
                 continue
             name = re.sub(r"\(anonymous namespace\)::|^void ", "", row["Kernel_Name"]).split("(")[0]
-            if name.startswith("env_step_kernel<") and name.rstrip().endswith("true>"):
+            if name.startswith("env_step_kernel<false") and name.rstrip().endswith("true>"):
+                name = "env_step_kernel_w1000_dr"  # <W10 = false, DR = true>: the train loop's instantiation
+            elif name.startswith("env_step_kernel<") and name.rstrip().endswith("true>"):
                 name = "env_step_kernel_dr"  # the domain-randomised instantiation <W10, DR = true>
             elif "gemm_rowln" not in name:  # the fused kernel keeps its template arguments: <JT, k-tiles> tell the shapes apart
                 name = name.split("<")[0]
@@ -29,7 +31,8 @@ fetch = collect(sys.argv[1], "FETCH_SIZE")
 write = collect(sys.argv[2], "WRITE_SIZE")
 out = defaultdict(dict)
 for (name, grid), f in fetch.items():
-    if (name, grid) not in write or not ("env_step" in name or "gemm_kernel" in name or "gemm_rowln" in name or "actor_rows" in name):
+    if (name, grid) not in write or not ("env_step" in name or "gemm_kernel" in name or "gemm_rowln" in name or "actor_rows" in name
+                                         or "actor_split" in name):
         continue
     w = write[(name, grid)]
     out[name][str(grid)] = {"lib_sources_sha256": SHA, "fetch_size_kib_raw": f, "write_size_kib": w, "hbm_read_bytes": f * 1024 * 2,

@@ -1,0 +1,58 @@
+#!/bin/bash
+# round-3 profile set (one gpurun call): kernel stats of the train loop (rocprofv3 --kernel-trace --stats), the update's kernel
+# sequence, PMC traffic passes (FETCH_SIZE / WRITE_SIZE in separate runs), the bench matrix and the default bench line.
+# Everything lands in gpurun_out/r03/; the summaries are then copied into profiles/ by hand.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r03; rm -rf $O; mkdir -p $O
+python bench.py > $O/default_bench.json 2> $O/default_bench.err; echo "default bench rc=$?"
+for n in 65536 8192 4096; do
+  extra=""; [ $n -lt 65536 ] && extra="--segments on"
+  rm -rf /tmp/ks_$n
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$n -- python3 bench.py --loop-only --envs-per-gpu $n --steps 100 --warmup 20 $extra > $O/loop_$n.log 2>&1; echo "kernel stats $n rc=$?"
+  f=$(find /tmp/ks_$n -name "*kernel_stats.csv" | head -1); cp $f $O/train_loop_kernel_stats_$n.csv
+  python3 tools/loop_stats_to_json.py $f $n $O/train_loop_kernel_stats.json > /dev/null
+done
+rm -rf /tmp/upd; timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/upd -- python3 tools/learner_only.py 30 0 0.1 > $O/upd.log 2>&1
+(cd tools && python3 update_timeline.py $(find /tmp/upd -name "*kernel_trace.csv" | head -1) ../$O/update_timeline.md > /dev/null 2>&1); echo "update timeline rc=$?"
+python tools/update_bench.py > $O/update_bench.json 2>/dev/null
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c/a -- python3 tools/pmc_run.py envdr1000 65536 > $O/pmc_$c.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c/b -- python3 tools/pmc_run.py envdr 65536 4194304 >> $O/pmc_$c.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c/c -- python3 tools/pmc_run.py act 4096 8192 32768 65536 >> $O/pmc_$c.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c/d -- python3 tools/pmc_run.py env 65536 4194304 >> $O/pmc_$c.log 2>&1
+  echo "pmc $c done"
+done
+cp profiles/pmc_traffic.json $O/pmc_traffic.json
+python3 tools/pmc_to_json.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $O/pmc_traffic.json > /dev/null; echo "pmc json rc=$?"
+{
+echo "| workload | env-steps/s | ms/step | SAC updates/s | flags |"; echo "|---|---|---|---|---|"
+run() { python bench.py --loop-only "$@" 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('| %s | %.3g | %.4f | %s | %s |' % (d['config']['workload'].split(',')[0], d['value'], d['ms_per_step'], ('%.0f' % d['sac_updates_per_s']) if 'sac_updates_per_s' in d else '-', sys.argv[1]))" "$*"; }
+run --workload train --envs-per-gpu 4096 --steps 300 --warmup 30
+run --workload train --envs-per-gpu 4096 --steps 300 --warmup 30 --segments on
+run --workload train --envs-per-gpu 4096 --steps 300 --warmup 30 --graph
+run --workload train --envs-per-gpu 8192 --steps 300 --warmup 30
+run --workload train --envs-per-gpu 8192 --steps 300 --warmup 30 --segments on
+run --workload train --envs-per-gpu 8192 --steps 300 --warmup 30 --graph
+run --workload train --envs-per-gpu 16384 --steps 300 --warmup 30
+run --workload train --envs-per-gpu 32768 --steps 300 --warmup 30
+run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30
+run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --segments on
+run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --acting-dropout
+run --workload train --envs-per-gpu 4096 --steps 300 --warmup 30 --acting-dropout --segments on
+run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --updates-per-step 2
+run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --updates-per-step 4
+run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --dr-stage 0
+run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --shipped-acting
+run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --family 1
+run --workload train --envs-per-gpu 4096 --steps 300 --warmup 30 --family 1 --segments on
+run --workload physics --envs-per-gpu 65536 --steps 2000 --warmup 100
+run --workload physics --envs-per-gpu 4194304 --steps 100 --warmup 10
+} > $O/bench_matrix.md
+python tools/env_dr_bench.py > $O/env_dr_bench.jsonl 2>/dev/null
+echo "--- act bench" > $O/act_bench.txt; python tools/act_bench.py 1024 4096 8192 12288 16384 32768 65536 2>/dev/null | grep -v "^ *$" >> $O/act_bench.txt
+cp gpurun_out/parity_summary.json $O/parity_summary.json 2>/dev/null
+ls $O
