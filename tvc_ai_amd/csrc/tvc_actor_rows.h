@@ -63,6 +63,9 @@ struct ArPipe {
     int wave;        // wave index in the workgroup, wave-uniform (readfirstlane): LDS destinations and M0 stay in SGPRs
     unsigned goff;   // this lane's byte offset inside a tile, (wave * 256 + lane) * 16: ONE 32-bit VGPR next to a scalar tile base
 };
+#ifndef AR_NW
+#define AR_NW 4     // waves (16 rows each) per workgroup sharing one tile stream: 4 = 64 rows; 8 = 128 rows (experiment, profiles/r03_d_actor_rows.md)
+#endif
 #ifndef AR_NBUF
 #define AR_NBUF 2   // LDS tile buffers: 2 = copy one tile ahead; 4 = copy two tiles ahead (experiment, profiles/r02_c_actor_rows.md)
 #endif
@@ -71,13 +74,15 @@ __device__ __forceinline__ void ar_issue_tile(const ArPipe& p, int ti) {
     // scalar tile base + 32-bit lane offset (the saddr form of the load): a per-lane 64-bit address would be one more live VGPR
     // pair in a kernel that sits at the register limit, and it was being spilled and reloaded once per tile
     const char* src = reinterpret_cast<const char*>(p.tiles) + ((size_t)__builtin_amdgcn_readfirstlane(ti) << 14) + p.goff;
-    float4* dst = p.Bs + (ti & (AR_NBUF - 1)) * AR_TILE_F4 + p.wave * 256;
+    float4* dst = p.Bs + (ti & (AR_NBUF - 1)) * AR_TILE_F4 + p.wave * (1024 / AR_NW);
     // one address pair; the four 1 KB pieces go through the instruction's immediate offset, which advances both the global and
     // the LDS address (checked by tools/micro/mfma_lds.hip) -- separate pointers cost an M0 write + readfirstlane per piece (-3 %)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 1024, 0);
+#if AR_NW == 4
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 2048, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 3072, 0);
+#endif
 }
 // Make tile p.ti readable, start the copy of tile p.ti + 1 into the buffer that tile p.ti - 1 just vacated, return the readable
 // tile.  __syncthreads() here is: wait for my quarter of tile ti (vmcnt(0): the LDS-DMA is a pending LDS write) and for my
@@ -217,10 +222,14 @@ __device__ __forceinline__ void ar_layernorm(f32x4* __restrict__ u, const float*
     }
 }
 
+#if AR_NW == 4
 __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
+#else
+__global__ void __launch_bounds__(64 * AR_NW) actor_rows_kernel(ActRowsArgs a) {
+#endif
     __shared__ __attribute__((aligned(16))) float4 Bs[AR_NBUF * AR_TILE_F4];  // the ONLY LDS object: the 16 KB weight-tile buffers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
-    const int row = blockIdx.x * 64 + wave * 16 + l15;
+    const int row = blockIdx.x * (16 * AR_NW) + wave * 16 + l15;
     const int rowc = min(row, a.M - 1);
     if (a.stamps && tid == 0) {
         unsigned xcc, hw;
@@ -232,7 +241,7 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
         a.stamps[AR_STAMPS * blockIdx.x + 5] = hw;
     }
     int tr = 6; (void)tr;  // AR_TRACE: stamps 6.. = s_memtime after every pass / epilogue of wave 0
-    ArPipe p{a.tiles, Bs, 0, a.n_tiles, __builtin_amdgcn_readfirstlane(wave), (unsigned)((wave * 256 + lane) * 16)};
+    ArPipe p{a.tiles, Bs, 0, a.n_tiles, __builtin_amdgcn_readfirstlane(wave), (unsigned)((wave * (1024 / AR_NW) + lane) * 16)};
     ar_issue_tile(p, 0);
 #if AR_NBUF > 2
     ar_issue_tile(p, 1);

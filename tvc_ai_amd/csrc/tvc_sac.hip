@@ -902,6 +902,8 @@ struct tvc_sac {
     PackVec* d_pvecs = nullptr;
     // ... and the stream of the net AS TRAINED (attention and embedding not folded) for train-mode acting (actor_split_kernel<true>)
     bool train_rows_ok = false;
+    bool train_stream_live = false;  // packed (and re-packed by every policy update, copied by every snapshot) only once train-mode
+                                     // acting has been asked for: the default loop does not pay for a stream it never reads
     int trows_tiles = 0, trows_vecs = 0;
     long tpack_floats = 0;
     float *tpack = nullptr, *snap_tpack = nullptr;  // [trows_tiles * 4096 tile floats | train vector section]
@@ -1304,6 +1306,20 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
         if (!h->dctx_ok) return tvc::set_error(TVC_EINVAL, "train-mode acting needs family 0 with dropout_p > 0");
         if (h->train_rows_ok && n >= split_min_rows() && g_force_variant == 0) {
             // one launch: the split kernel's TRAIN instantiation on the stream of the net as trained (tvc_actor_split.h)
+            if (!h->train_stream_live) {  // first request: pack that stream now; from here on every policy update re-packs it
+                h->train_stream_live = true;
+                const float* P = h->P_actor();
+                HeadPack hp{P + h->head_off[0], P + h->head_off[1], P + h->head_off[2], P + h->head_off[3], 2 * A,
+                            h->pack + (long)h->rows_tiles * 4096 + (long)h->cfg.n_layers * AR_LAYER_VEC,
+                            h->tpack + (long)h->trows_tiles * 4096 + 256 + 512L * h->cfg.n_layers};
+                PackSet none{nullptr, 0, nullptr, 0, nullptr, nullptr};
+                PackSet s1{h->d_tptiles, h->trows_tiles, h->d_tpvecs, h->trows_vecs, reinterpret_cast<float4*>(h->tpack),
+                           h->tpack + (long)h->trows_tiles * 4096};
+                hipLaunchKernelGGL(pack_actor_kernel, dim3(s1.n_tiles + s1.n_vecs + 1), dim3(256), 0, st, P, h->ov, none, s1, hp,
+                                   Ticks{nullptr, 0.f, 0.f, nullptr});
+                // (the snapshot, if one is being read, was taken before this stream existed: it holds the same parameters)
+                TVC_HIP_CHECK(hipMemcpyAsync(h->snap_tpack, h->tpack, h->tpack_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
             const float* pk = snap ? h->snap_pack : h->pack;
             const float* tpk = snap ? h->snap_tpack : h->tpack;
             ActRowsArgs a{};
@@ -1359,7 +1375,7 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
             }
             dyn_lds = 65536;
         }
-        hipLaunchKernelGGL(actor_rows_kernel, dim3((n + 63) / 64), dim3(256), dyn_lds, st, a);
+        hipLaunchKernelGGL(actor_rows_kernel, dim3((n + 16 * AR_NW - 1) / (16 * AR_NW)), dim3(64 * AR_NW), dyn_lds, st, a);
         TVC_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -1401,7 +1417,7 @@ static int rows_probe(tvc_sac* h, const float* obs, int32_t n, int32_t launches,
     if (!h || !obs || n < 1 || launches < 1) return tvc::set_error(TVC_EINVAL, "bad argument");
     if (!h->rows_ok) return tvc::set_error(TVC_EINVAL, "this handle does not use the row-owner acting kernel");
     TVC_HIP_CHECK(hipSetDevice(h->device));
-    const int nwg = (n + 63) / 64, A = h->cfg.act_dim;
+    const int nwg = (n + 16 * AR_NW - 1) / (16 * AR_NW), A = h->cfg.act_dim;
     unsigned long long* st = nullptr;
     float* act = nullptr;
     TVC_HIP_CHECK(hipMalloc((void**)&st, (size_t)nwg * AR_STAMPS * sizeof(unsigned long long)));
@@ -1422,7 +1438,7 @@ int tvc_debug_rows_clock(tvc_sac* h, const float* obs, int32_t n, int32_t launch
     if (!out) return tvc::set_error(TVC_EINVAL, "bad argument");
     std::vector<unsigned long long> v;
     if (int rc = rows_probe(h, obs, n, launches, 0, v, stream)) return rc;
-    const int nwg = (n + 63) / 64;
+    const int nwg = (n + 16 * AR_NW - 1) / (16 * AR_NW);
     std::vector<double> mhz, life;
     for (int b = 0; b < nwg; ++b) {
         const double dc = (double)(v[AR_STAMPS * b + 2] - v[AR_STAMPS * b]), dr = (double)(v[AR_STAMPS * b + 3] - v[AR_STAMPS * b + 1]);
@@ -1618,8 +1634,10 @@ static void refresh_folded(tvc_sac* h, hipStream_t st, AdamClock* tick) {
                     h->train_rows_ok ? h->tpack + (long)h->trows_tiles * 4096 + 256 + 512L * c.n_layers : nullptr};
         PackSet s0{h->d_ptiles, h->rows_tiles, h->d_pvecs, h->rows_vecs, reinterpret_cast<float4*>(h->pack),
                    h->pack + (long)h->rows_tiles * 4096};
-        PackSet s1{h->d_tptiles, h->train_rows_ok ? h->trows_tiles : 0, h->d_tpvecs, h->train_rows_ok ? h->trows_vecs : 0,
-                   reinterpret_cast<float4*>(h->tpack), h->train_rows_ok ? h->tpack + (long)h->trows_tiles * 4096 : nullptr};
+        const bool tl = h->train_rows_ok && h->train_stream_live;
+        if (!tl) hp.tail_t = nullptr;
+        PackSet s1{h->d_tptiles, tl ? h->trows_tiles : 0, h->d_tpvecs, tl ? h->trows_vecs : 0,
+                   reinterpret_cast<float4*>(h->tpack), tl ? h->tpack + (long)h->trows_tiles * 4096 : nullptr};
         hipLaunchKernelGGL(pack_actor_kernel, dim3(s0.n_tiles + s0.n_vecs + s1.n_tiles + s1.n_vecs + 1), dim3(256), 0, st,
                            h->P_actor(), h->ov, s0, s1, hp, tk);
     }
@@ -1680,7 +1698,7 @@ int tvc_sac_snapshot_policy(tvc_sac* h, void* stream) {
     TVC_HIP_CHECK(hipMemcpyAsync(h->snap_p, h->P_actor(), h->n_actor * sizeof(float), hipMemcpyDeviceToDevice, st));
     TVC_HIP_CHECK(hipMemcpyAsync(h->snap_ov, h->ov, h->ov_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (h->rows_ok) TVC_HIP_CHECK(hipMemcpyAsync(h->snap_pack, h->pack, h->pack_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (h->train_rows_ok)
+    if (h->train_rows_ok && h->train_stream_live)
         TVC_HIP_CHECK(hipMemcpyAsync(h->snap_tpack, h->tpack, h->tpack_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
     return 0;
 }
