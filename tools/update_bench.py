@@ -17,6 +17,6 @@ bt = (torch.randn(B, 10, device=dev), torch.rand(B, 2, device=dev) * 2 - 1, torc
       torch.randn(B, 10, device=dev), torch.zeros(B, device=dev), torch.randn(B, 2, device=dev), torch.randn(B, 2, device=dev))
 us = bench.graph_time_us(lambda k: sac.update(*bt), 20, dev)
 print(json.dumps({"family": family, "dropout_p": p, "us_per_update": us, "updates_per_s": 1e6 / us,
-                  "fold_ln": os.environ.get("TVC_FOLD_LN", "1"), "adam_steps": sac.adam_steps(),
+                  "fold_ln": os.environ.get("TVC_FOLD_LN", "0"), "ln_tail": os.environ.get("TVC_LN_TAIL", "1"), "adam_steps": sac.adam_steps(),
                   "losses": sac.losses.cpu().tolist()}), flush=True)
 sac.close()

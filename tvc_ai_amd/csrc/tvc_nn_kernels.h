@@ -1413,12 +1413,9 @@ struct LnArgs {
     const float* headW; const float* headB; float* headOut; int headN;
     long gHW, gHO;             // group strides of the head's parameters / output
 };
+// one row by one wave (lane = 0..63); x = the row's input
 template <int VPL>  // values per lane = N / 64
-__global__ void __launch_bounds__(256) layernorm_fwd_kernel(LnArgs a) {
-    TVC_LEARNER_PRIO();
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.M) return;
-    const long z = blockIdx.y;
+__device__ __forceinline__ void ln_fwd_row(const LnArgs& a, int row, long z, int lane) {
     const float* x = a.X + z * a.gX + (long)row * a.N;
     float v[VPL];
 #pragma unroll
@@ -1480,6 +1477,55 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(LnArgs a) {
         a.mean[z * a.gS + row] = mean;
         a.rstd[z * a.gS + row] = rstd;
     }
+}
+template <int VPL>
+__global__ void __launch_bounds__(256) layernorm_fwd_kernel(LnArgs a) {
+    TVC_LEARNER_PRIO();
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.M) return;
+    ln_fwd_row<VPL>(a, row, blockIdx.y, lane);
+}
+
+// LayerNorm(s) behind a Linear WITHOUT a launch of their own (update path): the Linear's output row is spread over gridDim.x
+// column-tile workgroups, each of which publishes its tile (release fence), then takes a ticket on the row tile's counter; the
+// workgroup that arrives LAST sees every tile (acquire fence) and normalises the 32 rows (8 per wave).  A second norm directly
+// behind the first (norm2 -> feature_norm) and the output head behind the last norm ride along.  The counter resets itself.
+struct LnTail {
+    unsigned* cnt;   // [groups x row tiles], zero between launches; nullptr: no tail
+    LnArgs n1, n2;   // n2.X == nullptr: one norm
+};
+template <int VPL>
+__device__ __forceinline__ void ln_tail(const LnTail& t, int m0, int rows, int tiles_x, unsigned cnt_index, long z) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this thread's tile stores are visible device-wide ...
+    __syncthreads();                                     // ... for every thread of the workgroup
+    __shared__ unsigned tail_last;
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(t.cnt + cnt_index, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tail_last = prev == (unsigned)tiles_x - 1u ? 1u : 0u;
+        if (tail_last) t.cnt[cnt_index] = 0u;  // ready for the next launch (stream order)
+    }
+    __syncthreads();
+    if (!tail_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, per = rows / 4;
+#pragma unroll 4
+    for (int r = 0; r < per; ++r) ln_fwd_row<VPL>(t.n1, m0 + wave * per + r, z, lane);
+    if (t.n2.X) {  // (each lane re-reads exactly the columns it wrote)
+#pragma unroll 4
+        for (int r = 0; r < per; ++r) ln_fwd_row<VPL>(t.n2, m0 + wave * per + r, z, lane);
+    }
+}
+
+// split-K Linear (fast path) + the LayerNorm(s) / output head behind it, one launch (ln_tail)
+template <int VPL>
+__global__ void TVC_SKINNY_BOUNDS gemm_skinny_lnt_kernel(GemmArgs g, LnTail t) {
+    warm_kernargs<sizeof(GemmArgs) + sizeof(LnTail)>();
+    TVC_LEARNER_PRIO();
+    __shared__ float red[4][32 * 33];
+    int bx, by;
+    xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y, bx, by);
+    skinny_body_fast<true, true>(g, bx, by, blockIdx.z, red);
+    ln_tail<VPL>(t, by * 32, 32, gridDim.x, blockIdx.z * gridDim.y + by, blockIdx.z);
 }
 
 // any width up to 1024 (inference helpers: the 128-wide norm of the hierarchical goal policy): strided columns per lane

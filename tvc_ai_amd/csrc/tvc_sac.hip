@@ -235,7 +235,9 @@ struct Ctx {
     std::vector<float*> Y, dY, Z, mean, rstd;  // per buffer index
     std::vector<float*> dYm;  // masked copy of dY for a Linear whose dropped output fed a residual add (dropout on)
     std::vector<long> gY;                       // group stride (elements) per buffer
+    unsigned* cnt = nullptr;                    // arrival counters of the Linear+LayerNorm launches (ln_tail), training contexts only
 };
+constexpr int kLnTailCounters = 256;
 
 static int fuse_ln_min_rows() {  // acting batches at least this large use the fused Linear+LayerNorm kernel
     static const int v = [] { const char* e = getenv("TVC_FUSE_LN_MIN_ROWS"); return e ? atoi(e) : 6144; }();
@@ -283,6 +285,16 @@ static void launch_gemm_ln(const GemmArgs& g, int G, hipStream_t st) {
     dim3 grid(g.N / 32, g.M / 32, G), block(256);
     if (g.K == 256) hipLaunchKernelGGL((gemm_skinny_ln_kernel<4>), grid, block, 0, st, g);
     else hipLaunchKernelGGL((gemm_skinny_ln_kernel<8>), grid, block, 0, st, g);
+}
+// Linear + the LayerNorm(s) / head behind it in one launch (the last column tile to arrive normalises the rows): update path
+static void launch_gemm_lnt(const GemmArgs& g, const LnTail& t, int G, hipStream_t st) {
+    dim3 grid(g.N / 32, g.M / 32, G), block(256);
+    if (g.N == 256) hipLaunchKernelGGL((gemm_skinny_lnt_kernel<4>), grid, block, 0, st, g, t);
+    else hipLaunchKernelGGL((gemm_skinny_lnt_kernel<8>), grid, block, 0, st, g, t);
+}
+static int ln_tail_enabled() {
+    static const int v = [] { const char* e = getenv("TVC_LN_TAIL"); return e ? atoi(e) : 1; }();
+    return v;
 }
 // TVC_FOLD_LN=1 computes the update's LayerNorms inside the consumer GEMM's operand load (13 launches fewer, 92 -> 79).  OFF by
 // default: measured SLOWER, 559 vs 535 us per update alone and 0.74 vs 0.71 ms per step at 4 096 envs (profiles/r03_c_update.md):
@@ -503,7 +515,42 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
                 launch_gemm_ln(g, G, st);
                 fold_n = 0;
             } else {
-                launch_gemm(true, true, g, G, st);
+                // LayerNorm(s) directly behind this Linear (and the output head behind them) finish inside its launch
+                const int nops = (int)nd.ops.size();
+                int nln = 0;
+                if (c.cnt && ln_tail_enabled() && g_force_variant == 0 && (o.out_dim == 256 || o.out_dim == 512) &&
+                    skinny_fast_ok(g) && (M / 32) * G <= kLnTailCounters) {
+                    while (nln < 2 && i + 1 + nln < nops && nd.ops[i + 1 + nln].type == OP_LN && nd.ops[i + 1 + nln].src == out + nln &&
+                           nd.ops[i + 1 + nln].out_dim == o.out_dim)
+                        ++nln;
+                }
+                if (nln > 0) {
+                    LnTail t{};
+                    t.cnt = c.cnt;
+                    for (int k = 0; k < nln; ++k) {
+                        const int li = i + 1 + k, lout = li + 1;
+                        const Op& l = nd.ops[li];
+                        LnArgs& a = k == 0 ? t.n1 : t.n2;
+                        a.X = c.Y[l.src]; a.Y = c.Y[lout]; a.gamma = P + l.w; a.beta = P + l.b;
+                        a.mean = save ? c.mean[lout] : nullptr; a.rstd = save ? c.rstd[lout] : nullptr;
+                        a.M = M; a.N = l.out_dim; a.gX = c.gY[l.src]; a.gY = c.gY[lout]; a.gP = gP; a.gS = M;
+                        a.drop = drop_args(dc, li, l.drop);
+                    }
+                    const int last = i + nln, lastout = last + 1;  // op index / buffer index of the last norm
+                    bool head = false;
+                    if (last + 1 < nops && nd.ops[last + 1].type == OP_HEAD && nd.ops[last + 1].src == lastout &&
+                        nd.ops[last + 1].out_dim <= 4) {
+                        const Op& ho = nd.ops[last + 1];
+                        LnArgs& a = nln == 1 ? t.n1 : t.n2;
+                        a.headW = P + ho.w; a.headB = P + ho.b; a.headOut = c.Y[lastout + 1]; a.headN = ho.out_dim;
+                        a.gHW = gP; a.gHO = c.gY[lastout + 1];
+                        head = true;
+                    }
+                    launch_gemm_lnt(g, t, G, st);
+                    i += nln + (head ? 1 : 0);
+                } else {
+                    launch_gemm(true, true, g, G, st);
+                }
             }
         } else if (o.type == OP_LN) {
             LnArgs a{};
@@ -1035,6 +1082,7 @@ static long ctx_bytes(const NetDef& nd, int M, int G, bool train) {
         f += train ? 2L * G * M : 0;                         // mean, rstd
     }
     f += (long)G * M * nd.buf_dim[0];  // dY[0]
+    f += train ? kLnTailCounters : 0;
     return f * 4;
 }
 static char* carve(char*& p, long bytes) {
@@ -1047,6 +1095,7 @@ static void ctx_alloc_train(Ctx& c, const NetDef& nd, int M, int G, char*& p) {
     c.M = M; c.G = G;
     c.Y.assign(nb, nullptr); c.dY.assign(nb, nullptr); c.Z.assign(nb, nullptr); c.dYm.assign(nb, nullptr);
     c.mean.assign(nb, nullptr); c.rstd.assign(nb, nullptr); c.gY.assign(nb, 0);
+    c.cnt = (unsigned*)carve(p, kLnTailCounters * 4);  // (the slab is zeroed at creation; every launch leaves them at zero)
     for (size_t b = 0; b < nb; ++b) {
         const long n = (long)M * nd.buf_dim[b];
         c.gY[b] = n;

@@ -64,6 +64,10 @@ class VecTrainer:
         # 2 and 4 updates per step, the update ends ~0.2 ms earlier at 1 (tools/ab_prio.sh)
         self._side = torch.cuda.Stream(self.device, priority=int(os.environ.get("TVC_SIDE_PRIORITY", "-1")))
         self._fork = torch.cuda.Event()
+        # the host may not run more than this many steps ahead of the device (0 = unbounded): a loop that never reads anything back
+        # would otherwise fill the launch queues, and a full queue is waited on far less efficiently than an event
+        self.max_steps_in_flight = int(os.environ.get("TVC_STEPS_IN_FLIGHT", "4"))
+        self._inflight = [torch.cuda.Event() for _ in range(max(0, self.max_steps_in_flight))]
         self._side_done = None  # timing event at the end of the learner's stream (tune_share_rows)
         # acting_dropout = True: act in train mode like the reference's get_action (agent/...:765): Dropout live in the policy
         # (attention not folded; one launch from 1 024 rows: actor_split_kernel<true>); False = the deterministic folded net
@@ -214,7 +218,20 @@ class VecTrainer:
         gs = self.sync.grad_scale if self.sync is not None else 1.0
         return self.sac.update(s, a, r, s2, d, self.eps1[k], self.eps2[k], all_reduce=self.sync, grad_scale=gs)
 
+    def _throttle(self):
+        """wait (on the host) for the step issued max_steps_in_flight steps ago; call _throttle_mark() at the end of the step"""
+        if self._inflight and self.steps >= len(self._inflight) and not torch.cuda.is_current_stream_capturing():
+            self._inflight[self.steps % len(self._inflight)].synchronize()
+
+    def _throttle_mark(self):
+        if self._inflight and not torch.cuda.is_current_stream_capturing():
+            self._inflight[self.steps % len(self._inflight)].record(torch.cuda.current_stream(self.device))
+
     def step(self, learn: bool = True):
+        self._throttle()
+        self._step(learn)
+
+    def _step(self, learn: bool = True):
         if learn and self.steps > 0:
             self._step_pipelined(two_streams=self.overlap)
         else:  # first step (empty replay) / pure collection
@@ -224,6 +241,7 @@ class VecTrainer:
             if learn:
                 for k in range(self.updates_per_step):
                     self.learn(k)
+        self._throttle_mark()
         self.steps += 1
         if self.curriculum is not None and not torch.cuda.is_current_stream_capturing():
             self._curriculum_tick()  # host-side bookkeeping (event query, pinned read-back): not part of a captured graph
@@ -378,6 +396,7 @@ class VecTrainer:
         n_pol = sac.n_policy
 
         def step_fn():
+            self._throttle()
             main = torch.cuda.current_stream(dev)
             g = sets[(self.steps - steps0) & 1]
             main.wait_stream(side)        # previous update done: its parameters are what A snapshots
@@ -396,6 +415,7 @@ class VecTrainer:
                     self._side_done.record(side)
             if not self.defer_join:
                 main.wait_stream(side)
+            self._throttle_mark()
             self.cur = 1 - self.cur
             self.steps += 1
             if self.curriculum is not None:
