@@ -27,9 +27,20 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Hardware queues: the train step needs the stream it is issued from, the learner's stream and (data parallel) RCCL's stream on
+# DIFFERENT hardware queues; ROCm's default of 4 is shared with every other stream the process touches (tvc_ai_amd/streams.py probes
+# the learner's stream; RCCL's is PyTorch's to choose).  Read by the HIP runtime when it initialises, hence before `import torch`.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+
+
+
+def _capture_stream(device):
+    from tvc_ai_amd.streams import capture_stream  # one capture stream per process and device (see streams.py: hardware queues)
+    return capture_stream(device)
+
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak (= fp32 vector peak)
@@ -265,7 +276,7 @@ def timed_steps(step_fn, K, W, world, device, use_graph):
     if use_graph:
         try:
             graph = torch.cuda.CUDAGraph()
-            side = torch.cuda.Stream(device)
+            side = _capture_stream(device)
             side.wait_stream(torch.cuda.current_stream(device))
             with torch.cuda.stream(side):
                 with torch.cuda.graph(graph, stream=side):
@@ -496,7 +507,7 @@ def graph_time_us(fn, reps, device, rounds=5):
         fn(0)
     torch.cuda.synchronize(device)
     g = torch.cuda.CUDAGraph()
-    side = torch.cuda.Stream(device)
+    side = _capture_stream(device)
     side.wait_stream(torch.cuda.current_stream(device))
     with torch.cuda.stream(side):
         with torch.cuda.graph(g, stream=side):

@@ -7,8 +7,11 @@ every XCD) and handed to torch as ExternalStreams.
 """
 import ctypes
 import json
+import os
 import sys
 import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 
@@ -51,11 +54,11 @@ def run(n, main_mask, side_mask, steps=300, segments=False):
 
 
 if __name__ == "__main__":
-    sizes = [int(a) for a in sys.argv[1:]] or [4096, 8192]
-    cases = [(None, None), ((0, 64), (64, 256)), ((0, 128), (128, 256)), ((0, 64), None), ((0, 128), None), ((0, 96), (96, 256)),
-             (None, (128, 256))]
-    for n in sizes:
-        for seg in (False, True):
-            for mm, sm in cases:
-                ms = run(n, mm, sm, segments=seg)
-                print(json.dumps({"n": n, "segments": seg, "main_mask": mm, "side_mask": sm, "ms_per_step": round(ms, 4)}), flush=True)
+    # one configuration per process (streams created by earlier cases would share hardware queues with later ones):
+    #   cumask_shard.py <n_envs> <segments 0|1> <main lo> <main hi> <side lo> <side hi>     (-1 -1 = unmasked)
+    n, seg = int(sys.argv[1]), bool(int(sys.argv[2]))
+    m = [int(a) for a in sys.argv[3:7]]
+    mm = None if m[0] < 0 else (m[0], m[1])
+    sm = None if m[2] < 0 else (m[2], m[3])
+    ms = run(n, mm, sm, segments=seg)
+    print(json.dumps({"n": n, "segments": seg, "main_mask": mm, "side_mask": sm, "ms_per_step": round(ms, 4)}), flush=True)

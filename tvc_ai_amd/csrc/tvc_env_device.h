@@ -11,6 +11,9 @@
 // "Physics restatement"); it is algebraically simplified for Ixx == Iyy (the m*w x v term of the
 // articulated-body form cancels against the frame-acceleration term).
 #pragma once
+#ifndef TVC_RING_BATCH
+#define TVC_RING_BATCH 32u  // loads in flight per thread in the 1000-entry reward-history scan (16 / 32 / 64: 57 / 49 / 53 us at 65 536 envs, tools/env_ring_bench.py)
+#endif
 #include <hip/hip_runtime.h>
 
 namespace tvcdev {
@@ -497,20 +500,39 @@ __device__ __forceinline__ void epilogue(Regs& r, float (&hw)[12], const DevCfg&
             for (int i = 0; i < 10; ++i) hw[i] = ((unsigned)i == slot) ? total : hw[i];
         } else {
             float ev = full ? ringp[(size_t)slot * np] : 0.0f;
-            // one pass over the env's ring, 16 independent loads at a time: the loop used to issue one load per iteration and
-            // wait for it -- with the rings full (1000 steps into a run) that was 1000 serial round trips per step, +0.4 ms on the
-            // 65 536-env train step (2.11 -> 2.52 ms; found in round 3, both earlier rounds quoted the first few hundred steps)
-            for (unsigned i0 = 0; i0 < wl; i0 += 16u) {
-                float hv[16];
+            // One pass over the env's ring, TVC_RING_BATCH independent loads at a time (the loop used to issue one load per iteration
+            // and wait for it -- with the rings full, 1000 steps into a run, that was 1000 serial round trips per step, +0.4 ms on the
+            // 65 536-env train step; found in round 3, both earlier rounds quoted the first few hundred steps).  Matches are COUNTED in
+            // two VGPRs over the whole window, the slot included (when full it holds ev, once): per-element `valid && equal`
+            // booleans are 64-bit lane masks in SGPRs, and beyond 16 of them hipcc serialised the loads again to save SGPRs
+            // (batch 32: 318 us instead of 81 at 65 536 envs, tools/env_ring_bench.py).
+            constexpr unsigned RB = TVC_RING_BATCH;
+            unsigned ce = 0u, cv = 0u;
+            const float* rp = ringp;
+            unsigned i0 = 0u;
+            for (; i0 + RB <= wl; i0 += RB) {
+                float hv[RB];
 #pragma unroll
-                for (unsigned u = 0; u < 16u; ++u) hv[u] = ringp[(size_t)min(i0 + u, wl - 1u) * np];
+                for (unsigned u = 0; u < RB; ++u) { hv[u] = *rp; rp += np; }
 #pragma unroll
-                for (unsigned u = 0; u < 16u; ++u) {
-                    const bool valid = (i0 + u) < wl && (i0 + u) != slot;
-                    e_dup |= valid && (hv[u] == ev);
-                    v_dup |= valid && (hv[u] == total);
+                for (unsigned u = 0; u < RB; ++u) {
+                    ce += hv[u] == ev ? 1u : 0u;
+                    cv += hv[u] == total ? 1u : 0u;
                 }
             }
+            if (i0 < wl) {  // the last, partial batch: clamped addresses, the entries past the window do not count
+                float hv[RB];
+#pragma unroll
+                for (unsigned u = 0; u < RB; ++u) hv[u] = ringp[(size_t)min(i0 + u, wl - 1u) * np];
+#pragma unroll
+                for (unsigned u = 0; u < RB; ++u) {
+                    const unsigned in = (i0 + u) < wl ? 1u : 0u;
+                    ce += hv[u] == ev ? in : 0u;
+                    cv += hv[u] == total ? in : 0u;
+                }
+            }
+            e_dup = ce >= 2u;                                       // (only read when full: the slot itself is one match)
+            v_dup = cv > ((full && ev == total) ? 1u : 0u);         // the slot is about to be overwritten: it does not count
             ringp[(size_t)slot * np] = total;
         }
         ring_slot = (int)slot;

@@ -703,6 +703,7 @@ __device__ __forceinline__ SkinnyPre4 skinny_prefetch4(const GemmArgs& g, long z
     p.kmask = drop_mix(c2 ^ (g.dmask.site * 0x9E3779B9u) ^ ((unsigned)z * 0x7F4A7C15u) ^ g.dmask.seed);
     return p;
 }
+template <bool COH = false>  // COH: C is published for other workgroups of THIS launch (ln_tail): device-scope write-through stores
 __device__ __forceinline__ void skinny_epilogue4(const GemmArgs& g, const f32x4 (&acc)[2][2], float (*red)[32 * 33], int m0, int n0, long z,
                                                  const SkinnyPre4& pre
 #ifdef TVC_GEMM_STAMPS
@@ -740,7 +741,12 @@ __device__ __forceinline__ void skinny_epilogue4(const GemmArgs& g, const f32x4 
     // stores last, back to back
     const long oo = (long)row * g.ldc + col0;
     if (g.Zout) *reinterpret_cast<float4*>(g.Zout + z * g.gZ + oo) = make_float4(zv[0], zv[1], zv[2], zv[3]);
-    *reinterpret_cast<float4*>(g.C + z * g.gC + oo) = make_float4(v[0], v[1], v[2], v[3]);
+    if (COH) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) __hip_atomic_store(g.C + z * g.gC + oo + c, v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        *reinterpret_cast<float4*>(g.C + z * g.gC + oo) = make_float4(v[0], v[1], v[2], v[3]);
+    }
     TVC_STAMP(g, 6);
 #ifdef TVC_GEMM_STAMPS
     __builtin_amdgcn_s_waitcnt(0x0070);  // stores acknowledged
@@ -796,7 +802,7 @@ __device__ __forceinline__ void skinny_mfma_chunk(const float (&a)[4][2][4], con
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i][j4], b[u][j][j4], acc[i][j], 0, 0, 0);
 }
-template <bool A_KC, bool B_KC>
+template <bool A_KC, bool B_KC, bool COH = false>
 __device__ __forceinline__ void skinny_body_fast(const GemmArgs& g, int bx, int by, long z, float (*red)[32 * 33]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = by * 32, n0 = bx * 32;
@@ -836,10 +842,10 @@ __device__ __forceinline__ void skinny_body_fast(const GemmArgs& g, int bx, int 
         }
     }
 #ifdef TVC_GEMM_STAMPS
-    skinny_epilogue4(g, acc, red, m0, n0, z, pre, tvc_st);
+    skinny_epilogue4<COH>(g, acc, red, m0, n0, z, pre, tvc_st);
     TVC_STAMP_FLUSH(g);
 #else
-    skinny_epilogue4(g, acc, red, m0, n0, z, pre);
+    skinny_epilogue4<COH>(g, acc, red, m0, n0, z, pre);
 #endif
 }
 // partial tiles of the four waves summed through LDS, then the shared epilogue and (optionally) bias-gradient column sums
@@ -1168,8 +1174,8 @@ __device__ __forceinline__ float thin_x(const ThinArgs& a, const float* X, const
     const float v = *p;
     return (k < a.K && row < a.M) ? v : 0.0f;
 }
-__global__ void __launch_bounds__(256) thin_fwd_kernel(ThinArgs a) {
-    TVC_LEARNER_PRIO();
+template <bool COH>  // COH: Y is published for other workgroups of this launch (ln_tail); full tiles only (M % 8 == 0, N % 256 == 0)
+__device__ __forceinline__ void thin_fwd_body(const ThinArgs& a) {
     __shared__ float xs[THIN_ROWS][THIN_K];
     const int tid = threadIdx.x, n = blockIdx.y * 256 + tid, row0 = blockIdx.x * THIN_ROWS;
     const long z = blockIdx.z;
@@ -1201,8 +1207,13 @@ __global__ void __launch_bounds__(256) thin_fwd_kernel(ThinArgs a) {
         if (Z) Z[o] = v;
         v = act_f(v, a.act);
         if (a.Mul) v *= a.Mul[z * a.gY + o];
-        Y[o] = v;
+        if (COH) __hip_atomic_store(Y + o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else Y[o] = v;
     }
+}
+__global__ void __launch_bounds__(256) thin_fwd_kernel(ThinArgs a) {
+    TVC_LEARNER_PRIO();
+    thin_fwd_body<false>(a);
 }
 // thin Linear + LayerNorm over exactly 256 output columns (one thread per column, the norm is a workgroup reduction per
 // row): the acting net's first block once the embedding and the first attention sublayer are folded into one
@@ -1414,14 +1425,20 @@ struct LnArgs {
     long gHW, gHO;             // group strides of the head's parameters / output
 };
 // one row by one wave (lane = 0..63); x = the row's input
-template <int VPL>  // values per lane = N / 64
+template <int VPL, bool COH = false>  // values per lane = N / 64; COH: X was written by other workgroups of this launch (ln_tail)
 __device__ __forceinline__ void ln_fwd_row(const LnArgs& a, int row, long z, int lane) {
     const float* x = a.X + z * a.gX + (long)row * a.N;
     float v[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; i += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(x + (i / 4) * 256 + lane * 4);
-        v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+        if (COH) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                v[i + j] = __hip_atomic_load(x + (i / 4) * 256 + lane * 4 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const float4 t = *reinterpret_cast<const float4*>(x + (i / 4) * 256 + lane * 4);
+            v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+        }
     }
     float s = 0.0f;
 #pragma unroll
@@ -1496,8 +1513,11 @@ struct LnTail {
 };
 template <int VPL>
 __device__ __forceinline__ void ln_tail(const LnTail& t, int m0, int rows, int tiles_x, unsigned cnt_index, long z) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // this thread's tile stores are visible device-wide ...
-    __syncthreads();                                     // ... for every thread of the workgroup
+    // The tile was stored with device-scope write-through stores (skinny_epilogue4<COH>) and is read back with device-scope loads:
+    // no cache maintenance.  (Plain stores + a device-scope release fence = buffer_wbl2, a write-back of the whole L2 by every
+    // workgroup: measured +15 us per launch, 752 instead of 536 us per update.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0): this thread's tile stores have been performed ...
+    __syncthreads();                                         // ... and so have those of every thread of the workgroup
     __shared__ unsigned tail_last;
     if (threadIdx.x == 0) {
         const unsigned prev = __hip_atomic_fetch_add(t.cnt + cnt_index, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1506,10 +1526,10 @@ __device__ __forceinline__ void ln_tail(const LnTail& t, int m0, int rows, int t
     }
     __syncthreads();
     if (!tail_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, per = rows / 4;
 #pragma unroll 4
-    for (int r = 0; r < per; ++r) ln_fwd_row<VPL>(t.n1, m0 + wave * per + r, z, lane);
+    for (int r = 0; r < per; ++r) ln_fwd_row<VPL, true>(t.n1, m0 + wave * per + r, z, lane);
     if (t.n2.X) {  // (each lane re-reads exactly the columns it wrote)
 #pragma unroll 4
         for (int r = 0; r < per; ++r) ln_fwd_row<VPL>(t.n2, m0 + wave * per + r, z, lane);
@@ -1524,8 +1544,102 @@ __global__ void TVC_SKINNY_BOUNDS gemm_skinny_lnt_kernel(GemmArgs g, LnTail t) {
     __shared__ float red[4][32 * 33];
     int bx, by;
     xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y, bx, by);
-    skinny_body_fast<true, true>(g, bx, by, blockIdx.z, red);
+    skinny_body_fast<true, true, true>(g, bx, by, blockIdx.z, red);
     ln_tail<VPL>(t, by * 32, 32, gridDim.x, blockIdx.z * gridDim.y + by, blockIdx.z);
+}
+
+// thin Linear (+act) + the LayerNorm behind it, ROW-COMPLETE: one workgroup owns 8 rows and all NC x 256 columns (thread t: columns
+// t, t + 256), so the norm is a workgroup reduction -- no hand-off between workgroups (the update's critics: Linear(12 -> 512),
+// GELU, LayerNorm(512), Dropout; with everything the backward needs saved: Z, the norm's input, mean / rstd).  Statistics two-pass
+// like layernorm_fwd_kernel (the partial sums meet in a different order: equal to fp32 rounding of a 512-term sum).
+template <int NC>
+__global__ void __launch_bounds__(256) thin_fwd_lnrow_kernel(ThinArgs a, LnArgs ln) {
+    TVC_LEARNER_PRIO();
+    __shared__ float xs[THIN_ROWS][THIN_K];
+    __shared__ float part[2][4][THIN_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row0 = blockIdx.x * THIN_ROWS;
+    const long z = blockIdx.z;
+    const float* X = a.X + z * a.gX;
+    const float* X2 = a.X2 ? a.X2 + z * a.gX2 : nullptr;
+    if (tid < THIN_ROWS * THIN_K) xs[tid / THIN_K][tid % THIN_K] = thin_x(a, X, X2, row0 + tid / THIN_K, tid % THIN_K);
+    float w[NC][THIN_K], b[NC], gm[NC], bt[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int n = c * 256 + tid;
+        const float* W = a.W + z * a.gW + (long)n * a.K;
+#pragma unroll
+        for (int k = 0; k < THIN_K; ++k) {
+            const float t = W[min(k, a.K - 1)];
+            w[c][k] = k < a.K ? t : 0.0f;
+        }
+        b[c] = a.bias ? a.bias[z * a.gB + n] : 0.0f;
+        gm[c] = ln.gamma[z * ln.gP + n];
+        bt[c] = ln.beta[z * ln.gP + n];
+    }
+    __syncthreads();
+    float* Yt = a.Y + z * a.gY;                     // the norm's input (kept for its backward)
+    float* Z = a.Z ? a.Z + z * a.gY : nullptr;
+    float v[THIN_ROWS][NC];
+#pragma unroll
+    for (int r = 0; r < THIN_ROWS; ++r) {
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float t = b[c];
+#pragma unroll
+            for (int k = 0; k < THIN_K; ++k) t = fmaf(xs[r][k], w[c][k], t);
+            const long o = (long)(row0 + r) * a.N + c * 256 + tid;
+            if (Z) Z[o] = t;
+            t = act_f(t, a.act);
+            Yt[o] = t;
+            v[r][c] = t;
+            s += t;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) part[0][wave][r] = s;
+    }
+    __syncthreads();
+    const float inv_n = 1.0f / (float)(NC * 256);
+    float mean[THIN_ROWS];
+#pragma unroll
+    for (int r = 0; r < THIN_ROWS; ++r) {
+        mean[r] = (part[0][0][r] + part[0][1][r] + part[0][2][r] + part[0][3][r]) * inv_n;
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { const float d = v[r][c] - mean[r]; s += d * d; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) part[1][wave][r] = s;
+    }
+    __syncthreads();
+    const unsigned key = ln.drop.ctr ? drop_key(ln.drop, (unsigned)z) : 0u;
+    float* Y = ln.Y + z * ln.gY;
+#pragma unroll
+    for (int r = 0; r < THIN_ROWS; ++r) {
+        const float rstd = rsqrtf((part[1][0][r] + part[1][1][r] + part[1][2][r] + part[1][3][r]) * inv_n + 1e-5f);
+        const int row = row0 + r;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int n = c * 256 + tid;
+            float o = (v[r][c] - mean[r]) * rstd * gm[c] + bt[c];
+            if (ln.drop.ctr) o *= drop_factor(ln.drop, key, row, n);
+            Y[(long)row * a.N + n] = o;
+        }
+        if (tid == 0 && ln.mean) {
+            ln.mean[z * ln.gS + row] = mean[r];
+            ln.rstd[z * ln.gS + row] = rstd;
+        }
+    }
+}
+
+// thin Linear (+act) + the LayerNorm behind it in one launch (the critics' first block): 8 rows x 256 columns per workgroup, the
+// last column block of a row group to arrive normalises its 8 rows
+template <int VPL>
+__global__ void __launch_bounds__(256) thin_fwd_lnt_kernel(ThinArgs a, LnTail t) {
+    TVC_LEARNER_PRIO();
+    thin_fwd_body<true>(a);
+    ln_tail<VPL>(t, blockIdx.x * THIN_ROWS, THIN_ROWS, gridDim.y, blockIdx.z * gridDim.x + blockIdx.x, blockIdx.z);
 }
 
 // any width up to 1024 (inference helpers: the 128-wide norm of the hierarchical goal policy): strided columns per lane

@@ -292,8 +292,12 @@ static void launch_gemm_lnt(const GemmArgs& g, const LnTail& t, int G, hipStream
     if (g.N == 256) hipLaunchKernelGGL((gemm_skinny_lnt_kernel<4>), grid, block, 0, st, g, t);
     else hipLaunchKernelGGL((gemm_skinny_lnt_kernel<8>), grid, block, 0, st, g, t);
 }
+static int thin_ln_enabled() {  // TVC_THIN_LN=0: input layer and its LayerNorm as two launches (A/B)
+    static const int v = [] { const char* e = getenv("TVC_THIN_LN"); return e ? atoi(e) : 1; }();
+    return v;
+}
 static int ln_tail_enabled() {
-    static const int v = [] { const char* e = getenv("TVC_LN_TAIL"); return e ? atoi(e) : 1; }();
+    static const int v = [] { const char* e = getenv("TVC_LN_TAIL"); return e ? atoi(e) : 0; }();
     return v;
 }
 // TVC_FOLD_LN=1 computes the update's LayerNorms inside the consumer GEMM's operand load (13 launches fewer, 92 -> 79).  OFF by
@@ -390,6 +394,40 @@ static int ln_fold_len(const NetDef& nd, int i, int M, bool dropping) {
 }
 
 // forward of one net (G parameter groups batched through blockIdx.z).  X: [G?][M,in]; gX = 0 shares one input.
+// LayerNorm ops (at most two) directly behind Linear op i, and the output head behind the last of them, as the tail of the
+// Linear's own launch (tvc_nn_kernels.h: ln_tail); returns how many norms ride along (0: none / not available)
+static int make_ln_tail(const NetDef& nd, int i, const float* P, long gP, int M, Ctx& c, bool save, const DropCtl* dc, LnTail& t,
+                        bool& head) {
+    const int nops = (int)nd.ops.size(), out = i + 1, width = nd.ops[i].out_dim;
+    head = false;
+    if (!c.cnt || !ln_tail_enabled() || g_force_variant != 0 || (width != 256 && width != 512)) return 0;
+    int nln = 0;
+    while (nln < 2 && i + 1 + nln < nops && nd.ops[i + 1 + nln].type == OP_LN && nd.ops[i + 1 + nln].src == out + nln &&
+           nd.ops[i + 1 + nln].out_dim == width)
+        ++nln;
+    if (nln == 0) return 0;
+    t = LnTail{};
+    t.cnt = c.cnt;
+    for (int k = 0; k < nln; ++k) {
+        const int li = i + 1 + k, lout = li + 1;
+        const Op& l = nd.ops[li];
+        LnArgs& a = k == 0 ? t.n1 : t.n2;
+        a.X = c.Y[l.src]; a.Y = c.Y[lout]; a.gamma = P + l.w; a.beta = P + l.b;
+        a.mean = save ? c.mean[lout] : nullptr; a.rstd = save ? c.rstd[lout] : nullptr;
+        a.M = M; a.N = l.out_dim; a.gX = c.gY[l.src]; a.gY = c.gY[lout]; a.gP = gP; a.gS = M;
+        a.drop = drop_args(dc, li, l.drop);
+    }
+    const int last = i + nln, lastout = last + 1;  // op index / buffer index of the last norm
+    if (last + 1 < nops && nd.ops[last + 1].type == OP_HEAD && nd.ops[last + 1].src == lastout && nd.ops[last + 1].out_dim <= 4) {
+        const Op& ho = nd.ops[last + 1];
+        LnArgs& a = nln == 1 ? t.n1 : t.n2;
+        a.headW = P + ho.w; a.headB = P + ho.b; a.headOut = c.Y[lastout + 1]; a.headN = ho.out_dim;
+        a.gHW = gP; a.gHO = c.gY[lastout + 1];
+        head = true;
+    }
+    return nln;
+}
+
 static void net_forward(const NetDef& nd, const float* P, long gP, const float* X, long gX, int M, int G, Ctx& c, bool save,
                         const float* pe, int pe_rows, hipStream_t st, const float* Pext = nullptr, const In2* in2 = nullptr,
                         const DropCtl* dc = nullptr) {
@@ -436,6 +474,36 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
                 hipLaunchKernelGGL(thin_fwd_ln_kernel, dim3((M + THIN_ROWS - 1) / THIN_ROWS), dim3(256), 0, st, a, P + ln.w, P + ln.b);
                 i += 1;
                 continue;
+            }
+            // update path: the LayerNorm (+ dropout) behind the input layer in the same launch, row-complete (the critics' first block)
+            if ((save || dc) && (M % THIN_ROWS) == 0 && (o.out_dim == 256 || o.out_dim == 512) && o.mul < 0 && !(o.rowtab && pe) &&
+                i + 1 < (int)nd.ops.size() && nd.ops[i + 1].type == OP_LN && nd.ops[i + 1].src == out &&
+                nd.ops[i + 1].out_dim == o.out_dim && thin_ln_enabled() &&
+                !(i + 2 < (int)nd.ops.size() && nd.ops[i + 2].type == OP_HEAD && nd.ops[i + 2].src == out + 1)) {
+                const Op& l = nd.ops[i + 1];
+                LnArgs ln{};
+                ln.X = a.Y; ln.Y = c.Y[out + 1]; ln.gamma = P + l.w; ln.beta = P + l.b;
+                ln.mean = save ? c.mean[out + 1] : nullptr; ln.rstd = save ? c.rstd[out + 1] : nullptr;
+                ln.M = M; ln.N = l.out_dim; ln.gX = c.gY[out]; ln.gY = c.gY[out + 1]; ln.gP = gP; ln.gS = M;
+                ln.drop = drop_args(dc, i + 1, l.drop);
+                const dim3 grid(M / THIN_ROWS, 1, G);
+                if (o.out_dim == 256) hipLaunchKernelGGL((thin_fwd_lnrow_kernel<1>), grid, dim3(256), 0, st, a, ln);
+                else hipLaunchKernelGGL((thin_fwd_lnrow_kernel<2>), grid, dim3(256), 0, st, a, ln);
+                i += 1;
+                continue;
+            }
+            {   // (experiment, TVC_LN_TAIL=1) the LayerNorm behind the input layer finished by the last column block to arrive
+                LnTail t{};
+                bool head = false;
+                const int nln = ((M % THIN_ROWS) == 0 && (M / THIN_ROWS) * G <= kLnTailCounters && !a.Mul)
+                                    ? make_ln_tail(nd, i, P, gP, M, c, save, dc, t, head) : 0;
+                if (nln > 0) {
+                    const dim3 grid(M / THIN_ROWS, o.out_dim / 256, G);
+                    if (o.out_dim == 256) hipLaunchKernelGGL((thin_fwd_lnt_kernel<4>), grid, dim3(256), 0, st, a, t);
+                    else hipLaunchKernelGGL((thin_fwd_lnt_kernel<8>), grid, dim3(256), 0, st, a, t);
+                    i += nln + (head ? 1 : 0);
+                    continue;
+                }
             }
             hipLaunchKernelGGL(thin_fwd_kernel, dim3((M + THIN_ROWS - 1) / THIN_ROWS, (o.out_dim + 255) / 256, G), dim3(256), 0, st, a);
             continue;
@@ -516,36 +584,11 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
                 fold_n = 0;
             } else {
                 // LayerNorm(s) directly behind this Linear (and the output head behind them) finish inside its launch
-                const int nops = (int)nd.ops.size();
-                int nln = 0;
-                if (c.cnt && ln_tail_enabled() && g_force_variant == 0 && (o.out_dim == 256 || o.out_dim == 512) &&
-                    skinny_fast_ok(g) && (M / 32) * G <= kLnTailCounters) {
-                    while (nln < 2 && i + 1 + nln < nops && nd.ops[i + 1 + nln].type == OP_LN && nd.ops[i + 1 + nln].src == out + nln &&
-                           nd.ops[i + 1 + nln].out_dim == o.out_dim)
-                        ++nln;
-                }
+                LnTail t{};
+                bool head = false;
+                const int nln = (skinny_fast_ok(g) && (M / 32) * G <= kLnTailCounters)
+                                    ? make_ln_tail(nd, i, P, gP, M, c, save, dc, t, head) : 0;
                 if (nln > 0) {
-                    LnTail t{};
-                    t.cnt = c.cnt;
-                    for (int k = 0; k < nln; ++k) {
-                        const int li = i + 1 + k, lout = li + 1;
-                        const Op& l = nd.ops[li];
-                        LnArgs& a = k == 0 ? t.n1 : t.n2;
-                        a.X = c.Y[l.src]; a.Y = c.Y[lout]; a.gamma = P + l.w; a.beta = P + l.b;
-                        a.mean = save ? c.mean[lout] : nullptr; a.rstd = save ? c.rstd[lout] : nullptr;
-                        a.M = M; a.N = l.out_dim; a.gX = c.gY[l.src]; a.gY = c.gY[lout]; a.gP = gP; a.gS = M;
-                        a.drop = drop_args(dc, li, l.drop);
-                    }
-                    const int last = i + nln, lastout = last + 1;  // op index / buffer index of the last norm
-                    bool head = false;
-                    if (last + 1 < nops && nd.ops[last + 1].type == OP_HEAD && nd.ops[last + 1].src == lastout &&
-                        nd.ops[last + 1].out_dim <= 4) {
-                        const Op& ho = nd.ops[last + 1];
-                        LnArgs& a = nln == 1 ? t.n1 : t.n2;
-                        a.headW = P + ho.w; a.headB = P + ho.b; a.headOut = c.Y[lastout + 1]; a.headN = ho.out_dim;
-                        a.gHW = gP; a.gHO = c.gY[lastout + 1];
-                        head = true;
-                    }
                     launch_gemm_lnt(g, t, G, st);
                     i += nln + (head ? 1 : 0);
                 } else {

@@ -15,9 +15,11 @@ import os
 
 import torch
 
+from .streams import capture_stream, learner_stream, report as stream_report
+
 from .agent import NativeSAC, ReplayBuffer, dropout_seed_of, sac_cfg
 from .env import VecRocketTVCEnv
-from .parallel import GradSync, broadcast_parameters
+from .parallel import GradSync, broadcast_parameters, collective_runs_beside
 
 
 class VecTrainer:
@@ -60,9 +62,10 @@ class VecTrainer:
         if share_rows is not None:  # explicit split (bench: chosen at warm-up by tune_share_rows, identically on every rank)
             self.share_rows = max(0, min(int(share_rows), num_envs))
         self.share_tuning = None
+        self.stream_tuning = None
         # the learner's stream: high HIP priority + raised wave priority inside its kernels (TVC_LEARNER_PRIO): -4 % on the step at
         # 2 and 4 updates per step, the update ends ~0.2 ms earlier at 1 (tools/ab_prio.sh)
-        self._side = torch.cuda.Stream(self.device, priority=int(os.environ.get("TVC_SIDE_PRIORITY", "-1")))
+        self._side = learner_stream(self.device)  # (one per process and device: streams.py)
         self._fork = torch.cuda.Event()
         # the host may not run more than this many steps ahead of the device (0 = unbounded): a loop that never reads anything back
         # would otherwise fill the launch queues, and a full queue is waited on far less efficiently than an event
@@ -317,7 +320,7 @@ class VecTrainer:
                 self.step(True)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
-        cap = torch.cuda.Stream(self.device)
+        cap = capture_stream(self.device)
         cap.wait_stream(torch.cuda.current_stream(self.device))
         steps0 = self.steps
         with torch.cuda.stream(cap):
@@ -356,7 +359,7 @@ class VecTrainer:
         # the eager loop has drawn nothing ahead: draw the inputs of the next step now, as graph A will from here on
         self._draw_update_inputs(self._sets[self.steps & 1])
         torch.cuda.synchronize(dev)
-        cap = torch.cuda.Stream(dev)
+        cap = capture_stream(dev)
         sets = []
         steps0, cur0 = self.steps, self.cur
         for par in range(2):
@@ -489,6 +492,42 @@ class VecTrainer:
                                      "choice; times are max over ranks"}
         return self.share_tuning
 
+    def tune_learner_stream(self, steps: int = 10, margin: float = 0.9):
+        """Keep the high-priority learner stream unless a NORMAL-priority one is clearly faster (step time below `margin` x): with
+        the hardware queues oversubscribed by other streams of the process a high-priority stream can cost 5x (streams.py).  Timed
+        like tune_share_rows (real train steps, max over ranks, every rank takes the same decision)."""
+        if not self.overlap:
+            return None
+        while self.steps < 2:
+            self.step(True)
+        cands = [("high", learner_stream(self.device, -1)), ("normal", learner_stream(self.device, 0))]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        res = {}
+        for name, st in cands:
+            torch.cuda.synchronize(self.device)
+            self._side = st
+            for _ in range(3):
+                self.step(True)
+            torch.cuda.synchronize(self.device)
+            e0.record()
+            for _ in range(steps):
+                self.step(True)
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+            e1.record()
+            torch.cuda.synchronize(self.device)
+            us = e0.elapsed_time(e1) * 1e3 / steps
+            if self.world > 1:
+                import torch.distributed as dist
+                t = torch.tensor([us], dtype=torch.float64, device=self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                us = float(t.item())
+            res[name] = us
+        pick = "normal" if res["normal"] < margin * res["high"] else "high"
+        torch.cuda.synchronize(self.device)
+        self._side = dict(cands)[pick]
+        self.stream_tuning = {"learner_stream_priority": pick, "us_per_step": res}
+        return self.stream_tuning
+
     # -- true resume (the reference's --resume is a stub, scripts/train.py:904-907): learner, env SoA state, current
     #    observations, replay contents and counters, and the device RNG state
     def state_dict(self):
@@ -612,6 +651,7 @@ def bench_train(args, world, rank, device, n_envs=None):
     # this bench reports)
     prefill = int(getattr(args, "prefill_steps", 1000))
     tr.prefill_env(prefill)
+    stream_tuning = tr.tune_learner_stream() if tr.overlap and not shipped else None
     tuning = None
     if int(getattr(args, "share_rows", -1)) < 0 and utd == 1 and not shipped and tr.share_cus and tr.overlap and tr.uses_rows_kernel():
         tuning = tr.tune_share_rows()  # measured split, identical on every rank (times are maximised over the ranks)
@@ -629,6 +669,9 @@ def bench_train(args, world, rank, device, n_envs=None):
                                                       if shipped else "SAC policy",
                                                       "reward_history_window": int(tr.env.cfg.distinct_window),
                                                       "env_prefill_steps": prefill,
+                                                      "streams": {**stream_report(), "tuning": stream_tuning,
+                                                                  "collective_runs_beside_acting": collective_runs_beside(
+                                                                      torch.cuda.current_stream(device), tr._side, device)},
                                                       "domain_randomisation": "off (shipped env)" if stage is None
                                                       else f"curriculum stage {stage} with the curriculum driver attached "
                                                            f"(device-side episode statistics): {env_over}"}}}
