@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 # Hardware queues: the train step needs the stream it is issued from, the learner's stream and (data parallel) RCCL's stream on
 # DIFFERENT hardware queues; ROCm's default of 4 is shared with every other stream the process touches (tvc_ai_amd/streams.py probes
 # the learner's stream; RCCL's is PyTorch's to choose).  Read by the HIP runtime when it initialises, hence before `import torch`.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -81,6 +81,9 @@ def parse():
                     help="train: one acting workgroup per CU so that the update runs beside the acting pass (auto: on with the two-stream schedule)")
     ap.add_argument("--share-rows", type=int, default=-1, help="train: rows the acting kernel handles in its CU-sharing form; -1 = "
                                                                "chosen at warm-up from measured step times (max over ranks)")
+    ap.add_argument("--cu-split", default="auto", help="train: CU partition of the step's two streams: auto = chosen at warm-up from "
+                                                       "measured step times below 12 288 envs per GPU; 0 = none; k = mask bits [0, k) "
+                                                       "for acting / env / replay, the rest for the update")
     ap.add_argument("--segments", choices=["auto", "on", "off"], default="auto",
                     help="train: replay the step as segment graphs between the update's collectives (auto: on with --gpus > 1, where "
                          "a whole-step graph cannot hold the RCCL calls)")
@@ -492,6 +495,7 @@ def shard_sizes(args, device, sizes=(4096, 8192), K=200, W=30):
             ent[mode] = {"ms_per_step": dt / K * 1e3, "sac_updates_per_s": K / dt, "env_steps_per_s": n * K / dt}  # the chip in a low clock state: best of two)
             if t.share_tuning is not None:
                 ent["share_rows"] = t.share_rows
+            ent["main_stream_cu_mask_bits"] = t.cu_split
             t.close()
         best = min(("segment_graphs", "eager"), key=lambda m: ent[m]["ms_per_step"])
         rep[str(n)] = {"ms_per_step": ent[best]["ms_per_step"], "sac_updates_per_s": ent[best]["sac_updates_per_s"],

@@ -192,6 +192,48 @@ def test_share_rows_tuning_picks_a_measured_split():
     tr.close()
 
 
+@pytest.mark.parametrize("segments", [False, True])
+def test_cu_partitioned_streams_do_the_same_work(segments):
+    """set_cu_split(): acting / env / replay on a CU-masked stream of the trainer's own, the update on the complementary mask (the
+    schedule bench.py may choose at BASELINE's per-GPU shard sizes).  Same seeds => the same loop as the unpartitioned steps."""
+    n, steps = 4096, 9
+    a = _run_loop(n, steps, 11, overlap=True, defer_join=True)
+    for _ in range(3):
+        a.step(True)
+    a.set_cu_split(96)
+    assert a.cu_split == 96 and a._main is not None
+    fn = a.capture_segments() if segments else (lambda: a.step(True))
+    for _ in range(steps - 3):
+        fn()
+    b = _run_loop(n, steps, 11, overlap=True)
+    for _ in range(steps):
+        b.step(True)
+    _compare(_finish(a), _finish(b), f"cu_split_96_vs_unpartitioned_{'segments' if segments else 'eager'}_{n}", n, steps,
+             counter_ahead=1 if segments else 0)
+
+
+def test_stream_and_cu_split_tuning_take_measured_decisions():
+    from tvc_ai_amd.trainer import VecTrainer
+    n = 4096
+    tr = VecTrainer(n, family=0, batch_size=256, replay_capacity=200_000, seed=3, overlap=True, defer_join=True)
+    st = tr.tune_learner_stream(steps=4)
+    assert st["learner_stream_priority"] in ("high", "normal") and all(v > 0 for v in st["us_per_step"].values())
+    cu = tr.tune_cu_split(candidates=(0, 96, 128), steps=4)
+    assert cu["main_stream_cu_mask_bits"] in (0, 96, 128) and tr.cu_split == cu["main_stream_cu_mask_bits"]
+    assert len(cu["candidates"]) == 3 and all(c["us_per_step"] > 0 for c in cu["candidates"])
+    for _ in range(3):
+        tr.step(True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr.sac.params).all()
+    with pytest.raises(ValueError):
+        tr.set_cu_split(100)  # not a multiple of 8 mask bits
+    tr.set_cu_split(0)
+    assert tr._main is None and tr.cu_split == 0
+    tr.step(True)
+    parity_log.record("stream_and_cu_split_tuning_4096", learner_stream=st, cu_split=cu)
+    tr.close()
+
+
 def test_update_without_passthrough_trains_the_sac_learner():
     """with the eager pass-through off (or algorithms.ppo.enabled: false) nothing is called 'ppo'; select_algorithm
     must then answer the first available algorithm, so that update(batch) under the reference's driver (scripts/train.py:577-606:

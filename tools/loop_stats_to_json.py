@@ -15,16 +15,19 @@ for r in csv.DictReader(open(src)):
     short = re.sub(r"\(anonymous namespace\)::", "", name)
     rows[short] = float(r["AverageNs"]) / 1e3
     rows.setdefault(re.sub(r"<.*$", "", short), float(r["AverageNs"]) / 1e3)
-# the acting pass is split into two launches per step since round 2 (half the rows beside the learner, half alone): store
-# the PER-STEP total under the plain kernel name so that it compares with one isolated launch over all rows
+# the acting pass is split into two launches per step since round 2 (some rows beside the learner, the rest alone): store the
+# PER-STEP total under the plain kernel name so that it compares with one isolated launch over all rows.  Steps = launches of a
+# kernel that runs exactly once per train step and never outside one (update_prep_kernel: one update per step; the env's own
+# step kernel also runs in the prefill).  Profile with a FIXED split (--share-rows): the tuning at warm-up runs other splits.
 calls = {r["Name"]: (int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(src))}
-steps = next((c for k, (c, _) in calls.items() if "env_step_kernel" in k), None)
+steps = next((c for k, (c, _) in calls.items() if "update_prep_kernel" in k), None)
 k = "tvcnn::actor_rows_kernel"
 full = next((n for n in calls if n.startswith(k)), None)
-if steps and full and calls[full][0] >= 2 * steps - 2:
+if steps and full and calls[full][0] > steps:
     rows[k + " [average of one launch]"] = rows[k]
-    rows[k] = calls[full][1] / 1e3 / (calls[full][0] / 2.0)
-    rows["_launches_per_step"] = {k: 2}
+    rows[k] = calls[full][1] / 1e3 / steps
+    rows["_launches_per_step"] = {k: calls[full][0] / steps}
+    rows["_train_steps_profiled"] = steps
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tvc_ai_amd.build import sources_sha256  # noqa: E402
 rows["_lib_sources_sha256"] = sources_sha256()  # bench.py prints "stale": true beside in_loop_us when the library has moved on

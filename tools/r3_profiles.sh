@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03; rm -rf $O; mkdir -p $O
 python bench.py > $O/default_bench.json 2> $O/default_bench.err; echo "default bench rc=$?"
 for n in 65536 8192 4096; do
-  extra=""; [ $n -lt 65536 ] && extra="--segments on"
+  extra="--share-rows 32768"; [ $n -lt 65536 ] && extra="--segments on"   # (a fixed split: the warm-up tuning would run other splits under the profiler)
   rm -rf /tmp/ks_$n
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$n -- python3 bench.py --loop-only --envs-per-gpu $n --steps 100 --warmup 20 $extra > $O/loop_$n.log 2>&1; echo "kernel stats $n rc=$?"
   f=$(find /tmp/ks_$n -name "*kernel_stats.csv" | head -1); cp $f $O/train_loop_kernel_stats_$n.csv

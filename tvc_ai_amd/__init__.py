@@ -8,7 +8,7 @@ import os as _os
 
 # hardware queues for the two-stream train step (tvc_ai_amd/streams.py): read by the HIP runtime when it initialises, so this only
 # takes effect if the process has not touched the GPU yet; an explicit setting of the user's wins
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from .env import (EnhancedRocketTVCEnv, VecRocketTVCEnv, make_debug_env, make_enhanced_tvc_env,  # noqa: F401
                   make_evaluation_env, make_training_env, CURRICULUM_STAGES, PHASE_NAMES, MissionPhase, MissionSuccess,

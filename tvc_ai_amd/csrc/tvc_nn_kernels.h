@@ -1174,8 +1174,8 @@ __device__ __forceinline__ float thin_x(const ThinArgs& a, const float* X, const
     const float v = *p;
     return (k < a.K && row < a.M) ? v : 0.0f;
 }
-template <bool COH>  // COH: Y is published for other workgroups of this launch (ln_tail); full tiles only (M % 8 == 0, N % 256 == 0)
-__device__ __forceinline__ void thin_fwd_body(const ThinArgs& a) {
+__global__ void __launch_bounds__(256) thin_fwd_kernel(ThinArgs a) {
+    TVC_LEARNER_PRIO();
     __shared__ float xs[THIN_ROWS][THIN_K];
     const int tid = threadIdx.x, n = blockIdx.y * 256 + tid, row0 = blockIdx.x * THIN_ROWS;
     const long z = blockIdx.z;
@@ -1207,13 +1207,8 @@ __device__ __forceinline__ void thin_fwd_body(const ThinArgs& a) {
         if (Z) Z[o] = v;
         v = act_f(v, a.act);
         if (a.Mul) v *= a.Mul[z * a.gY + o];
-        if (COH) __hip_atomic_store(Y + o, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else Y[o] = v;
+        Y[o] = v;
     }
-}
-__global__ void __launch_bounds__(256) thin_fwd_kernel(ThinArgs a) {
-    TVC_LEARNER_PRIO();
-    thin_fwd_body<false>(a);
 }
 // thin Linear + LayerNorm over exactly 256 output columns (one thread per column, the norm is a workgroup reduction per
 // row): the acting net's first block once the embedding and the first attention sublayer are folded into one
@@ -1546,100 +1541,6 @@ __global__ void TVC_SKINNY_BOUNDS gemm_skinny_lnt_kernel(GemmArgs g, LnTail t) {
     xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y, bx, by);
     skinny_body_fast<true, true, true>(g, bx, by, blockIdx.z, red);
     ln_tail<VPL>(t, by * 32, 32, gridDim.x, blockIdx.z * gridDim.y + by, blockIdx.z);
-}
-
-// thin Linear (+act) + the LayerNorm behind it, ROW-COMPLETE: one workgroup owns 8 rows and all NC x 256 columns (thread t: columns
-// t, t + 256), so the norm is a workgroup reduction -- no hand-off between workgroups (the update's critics: Linear(12 -> 512),
-// GELU, LayerNorm(512), Dropout; with everything the backward needs saved: Z, the norm's input, mean / rstd).  Statistics two-pass
-// like layernorm_fwd_kernel (the partial sums meet in a different order: equal to fp32 rounding of a 512-term sum).
-template <int NC>
-__global__ void __launch_bounds__(256) thin_fwd_lnrow_kernel(ThinArgs a, LnArgs ln) {
-    TVC_LEARNER_PRIO();
-    __shared__ float xs[THIN_ROWS][THIN_K];
-    __shared__ float part[2][4][THIN_ROWS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row0 = blockIdx.x * THIN_ROWS;
-    const long z = blockIdx.z;
-    const float* X = a.X + z * a.gX;
-    const float* X2 = a.X2 ? a.X2 + z * a.gX2 : nullptr;
-    if (tid < THIN_ROWS * THIN_K) xs[tid / THIN_K][tid % THIN_K] = thin_x(a, X, X2, row0 + tid / THIN_K, tid % THIN_K);
-    float w[NC][THIN_K], b[NC], gm[NC], bt[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const int n = c * 256 + tid;
-        const float* W = a.W + z * a.gW + (long)n * a.K;
-#pragma unroll
-        for (int k = 0; k < THIN_K; ++k) {
-            const float t = W[min(k, a.K - 1)];
-            w[c][k] = k < a.K ? t : 0.0f;
-        }
-        b[c] = a.bias ? a.bias[z * a.gB + n] : 0.0f;
-        gm[c] = ln.gamma[z * ln.gP + n];
-        bt[c] = ln.beta[z * ln.gP + n];
-    }
-    __syncthreads();
-    float* Yt = a.Y + z * a.gY;                     // the norm's input (kept for its backward)
-    float* Z = a.Z ? a.Z + z * a.gY : nullptr;
-    float v[THIN_ROWS][NC];
-#pragma unroll
-    for (int r = 0; r < THIN_ROWS; ++r) {
-        float s = 0.0f;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            float t = b[c];
-#pragma unroll
-            for (int k = 0; k < THIN_K; ++k) t = fmaf(xs[r][k], w[c][k], t);
-            const long o = (long)(row0 + r) * a.N + c * 256 + tid;
-            if (Z) Z[o] = t;
-            t = act_f(t, a.act);
-            Yt[o] = t;
-            v[r][c] = t;
-            s += t;
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) part[0][wave][r] = s;
-    }
-    __syncthreads();
-    const float inv_n = 1.0f / (float)(NC * 256);
-    float mean[THIN_ROWS];
-#pragma unroll
-    for (int r = 0; r < THIN_ROWS; ++r) {
-        mean[r] = (part[0][0][r] + part[0][1][r] + part[0][2][r] + part[0][3][r]) * inv_n;
-        float s = 0.0f;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) { const float d = v[r][c] - mean[r]; s += d * d; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) part[1][wave][r] = s;
-    }
-    __syncthreads();
-    const unsigned key = ln.drop.ctr ? drop_key(ln.drop, (unsigned)z) : 0u;
-    float* Y = ln.Y + z * ln.gY;
-#pragma unroll
-    for (int r = 0; r < THIN_ROWS; ++r) {
-        const float rstd = rsqrtf((part[1][0][r] + part[1][1][r] + part[1][2][r] + part[1][3][r]) * inv_n + 1e-5f);
-        const int row = row0 + r;
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int n = c * 256 + tid;
-            float o = (v[r][c] - mean[r]) * rstd * gm[c] + bt[c];
-            if (ln.drop.ctr) o *= drop_factor(ln.drop, key, row, n);
-            Y[(long)row * a.N + n] = o;
-        }
-        if (tid == 0 && ln.mean) {
-            ln.mean[z * ln.gS + row] = mean[r];
-            ln.rstd[z * ln.gS + row] = rstd;
-        }
-    }
-}
-
-// thin Linear (+act) + the LayerNorm behind it in one launch (the critics' first block): 8 rows x 256 columns per workgroup, the
-// last column block of a row group to arrive normalises its 8 rows
-template <int VPL>
-__global__ void __launch_bounds__(256) thin_fwd_lnt_kernel(ThinArgs a, LnTail t) {
-    TVC_LEARNER_PRIO();
-    thin_fwd_body<true>(a);
-    ln_tail<VPL>(t, blockIdx.x * THIN_ROWS, THIN_ROWS, gridDim.y, blockIdx.z * gridDim.x + blockIdx.x, blockIdx.z);
 }
 
 // any width up to 1024 (inference helpers: the 128-wide norm of the hierarchical goal policy): strided columns per lane

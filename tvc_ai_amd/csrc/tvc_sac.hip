@@ -292,10 +292,6 @@ static void launch_gemm_lnt(const GemmArgs& g, const LnTail& t, int G, hipStream
     if (g.N == 256) hipLaunchKernelGGL((gemm_skinny_lnt_kernel<4>), grid, block, 0, st, g, t);
     else hipLaunchKernelGGL((gemm_skinny_lnt_kernel<8>), grid, block, 0, st, g, t);
 }
-static int thin_ln_enabled() {  // TVC_THIN_LN=0: input layer and its LayerNorm as two launches (A/B)
-    static const int v = [] { const char* e = getenv("TVC_THIN_LN"); return e ? atoi(e) : 1; }();
-    return v;
-}
 static int ln_tail_enabled() {
     static const int v = [] { const char* e = getenv("TVC_LN_TAIL"); return e ? atoi(e) : 0; }();
     return v;
@@ -474,36 +470,6 @@ static void net_forward(const NetDef& nd, const float* P, long gP, const float* 
                 hipLaunchKernelGGL(thin_fwd_ln_kernel, dim3((M + THIN_ROWS - 1) / THIN_ROWS), dim3(256), 0, st, a, P + ln.w, P + ln.b);
                 i += 1;
                 continue;
-            }
-            // update path: the LayerNorm (+ dropout) behind the input layer in the same launch, row-complete (the critics' first block)
-            if ((save || dc) && (M % THIN_ROWS) == 0 && (o.out_dim == 256 || o.out_dim == 512) && o.mul < 0 && !(o.rowtab && pe) &&
-                i + 1 < (int)nd.ops.size() && nd.ops[i + 1].type == OP_LN && nd.ops[i + 1].src == out &&
-                nd.ops[i + 1].out_dim == o.out_dim && thin_ln_enabled() &&
-                !(i + 2 < (int)nd.ops.size() && nd.ops[i + 2].type == OP_HEAD && nd.ops[i + 2].src == out + 1)) {
-                const Op& l = nd.ops[i + 1];
-                LnArgs ln{};
-                ln.X = a.Y; ln.Y = c.Y[out + 1]; ln.gamma = P + l.w; ln.beta = P + l.b;
-                ln.mean = save ? c.mean[out + 1] : nullptr; ln.rstd = save ? c.rstd[out + 1] : nullptr;
-                ln.M = M; ln.N = l.out_dim; ln.gX = c.gY[out]; ln.gY = c.gY[out + 1]; ln.gP = gP; ln.gS = M;
-                ln.drop = drop_args(dc, i + 1, l.drop);
-                const dim3 grid(M / THIN_ROWS, 1, G);
-                if (o.out_dim == 256) hipLaunchKernelGGL((thin_fwd_lnrow_kernel<1>), grid, dim3(256), 0, st, a, ln);
-                else hipLaunchKernelGGL((thin_fwd_lnrow_kernel<2>), grid, dim3(256), 0, st, a, ln);
-                i += 1;
-                continue;
-            }
-            {   // (experiment, TVC_LN_TAIL=1) the LayerNorm behind the input layer finished by the last column block to arrive
-                LnTail t{};
-                bool head = false;
-                const int nln = ((M % THIN_ROWS) == 0 && (M / THIN_ROWS) * G <= kLnTailCounters && !a.Mul)
-                                    ? make_ln_tail(nd, i, P, gP, M, c, save, dc, t, head) : 0;
-                if (nln > 0) {
-                    const dim3 grid(M / THIN_ROWS, o.out_dim / 256, G);
-                    if (o.out_dim == 256) hipLaunchKernelGGL((thin_fwd_lnt_kernel<4>), grid, dim3(256), 0, st, a, t);
-                    else hipLaunchKernelGGL((thin_fwd_lnt_kernel<8>), grid, dim3(256), 0, st, a, t);
-                    i += nln + (head ? 1 : 0);
-                    continue;
-                }
             }
             hipLaunchKernelGGL(thin_fwd_kernel, dim3((M + THIN_ROWS - 1) / THIN_ROWS, (o.out_dim + 255) / 256, G), dim3(256), 0, st, a);
             continue;

@@ -15,7 +15,7 @@ import os
 
 import torch
 
-from .streams import capture_stream, learner_stream, report as stream_report
+from .streams import capture_stream, learner_stream, masked_stream, report as stream_report
 
 from .agent import NativeSAC, ReplayBuffer, dropout_seed_of, sac_cfg
 from .env import VecRocketTVCEnv
@@ -66,6 +66,9 @@ class VecTrainer:
         # the learner's stream: high HIP priority + raised wave priority inside its kernels (TVC_LEARNER_PRIO): -4 % on the step at
         # 2 and 4 updates per step, the update ends ~0.2 ms earlier at 1 (tools/ab_prio.sh)
         self._side = learner_stream(self.device)  # (one per process and device: streams.py)
+        self._main = None        # set_cu_split(): the step's own (CU-masked) stream instead of the caller's current stream
+        self.cu_split = 0
+        self.cu_tuning = None
         self._fork = torch.cuda.Event()
         # the host may not run more than this many steps ahead of the device (0 = unbounded): a loop that never reads anything back
         # would otherwise fill the launch queues, and a full queue is waited on far less efficiently than an event
@@ -230,9 +233,40 @@ class VecTrainer:
         if self._inflight and not torch.cuda.is_current_stream_capturing():
             self._inflight[self.steps % len(self._inflight)].record(torch.cuda.current_stream(self.device))
 
+    def set_cu_split(self, main_bits: int):
+        """Partition the chip between the two streams of the step: acting pass / env step / replay on the compute units of mask bits
+        [0, main_bits), the SAC update on the rest (0 = no partition: the caller's stream and the learner stream, whole chip).
+        At BASELINE's per-GPU shard sizes the step is bound by the update, whose ~90 latency-bound kernels take 1.3x their solo
+        time beside the acting kernel's 256 - 512 long-lived workgroups; with a slice of its own the update runs undisturbed and
+        the acting kernel still finishes inside it (4 096 envs: 0.72 -> 0.65 ms per step with 96 / 160, 8 192: 0.79 -> 0.68 with
+        128 / 128; tools/cumask_shard.py, profiles/r03_h_cu_split.md).  At 65 536 envs it loses (round 1).  Call between steps."""
+        torch.cuda.synchronize(self.device)
+        n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        k = int(main_bits)
+        if k <= 0:
+            self._main, self.cu_split = None, 0
+            self._side = learner_stream(self.device)
+            return
+        if k % 8 or not (8 <= k <= n_cu - 8):
+            raise ValueError(f"set_cu_split: a multiple of 8 in [8, {n_cu - 8}] (8 mask bits = one CU per XCD)")
+        self._main = masked_stream(self.device, 0, k)
+        self._side = masked_stream(self.device, k, n_cu)
+        self.cu_split = k
+
+    def _on_main(self, fn):
+        """run fn() on the step's own stream (when partitioned), ordered after / before the caller's stream"""
+        if self._main is None or torch.cuda.is_current_stream_capturing():
+            return fn()
+        caller = torch.cuda.current_stream(self.device)
+        self._main.wait_stream(caller)
+        with torch.cuda.stream(self._main):
+            out = fn()
+        caller.wait_stream(self._main)
+        return out
+
     def step(self, learn: bool = True):
         self._throttle()
-        self._step(learn)
+        self._on_main(lambda: self._step(learn))
 
     def _step(self, learn: bool = True):
         if learn and self.steps > 0:
@@ -395,12 +429,12 @@ class VecTrainer:
         self.cur = cur0  # capturing executed nothing (collect() flipped the double buffer twice: back where it was)
         assert self.steps == steps0
         torch.cuda.synchronize(dev)
-        side, sync = self._side, self.sync
+        sync = self.sync
         n_pol = sac.n_policy
 
-        def step_fn():
-            self._throttle()
+        def seg_step():
             main = torch.cuda.current_stream(dev)
+            side = self._side             # (read per step: set_cu_split / tune_learner_stream may have replaced it since the capture)
             g = sets[(self.steps - steps0) & 1]
             main.wait_stream(side)        # previous update done: its parameters are what A snapshots
             self._fork.record(main)       # ... and the batches drawn by the previous A are complete
@@ -423,6 +457,10 @@ class VecTrainer:
             self.steps += 1
             if self.curriculum is not None:
                 self._curriculum_tick()
+
+        def step_fn():
+            self._throttle()
+            self._on_main(seg_step)
 
         step_fn.graphs = sets
         return step_fn
@@ -491,6 +529,48 @@ class VecTrainer:
                              "note": "slack = main-stream end minus learner-stream end of a step (median of 5), measured after the "
                                      "choice; times are max over ranks"}
         return self.share_tuning
+
+    def tune_cu_split(self, candidates=(0, 96, 128), steps: int = 20):
+        """Choose the CU partition of the two streams (set_cu_split) from measured step times, like tune_share_rows (real train
+        steps in the deferred-join regime, max over ranks, every rank takes the same decision).  Only below 12 288 envs, where the
+        acting kernel needs at most two workgroups per CU of half the chip and the update is the critical path."""
+        if not self.overlap or self.hier is not None or self.n >= 12288 or not self.uses_rows_kernel():
+            return None
+        while self.steps < 2:
+            self.step(True)
+        dj = self.defer_join
+        self.defer_join = True
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        results = []
+        try:
+            for k in candidates:
+                self.set_cu_split(int(k))
+                for _ in range(3):
+                    self.step(True)
+                torch.cuda.synchronize(self.device)
+                e0.record()
+                for _ in range(steps):
+                    self.step(True)
+                torch.cuda.current_stream(self.device).wait_stream(self._side)
+                e1.record()
+                torch.cuda.synchronize(self.device)
+                us = e0.elapsed_time(e1) * 1e3 / steps
+                if self.world > 1:
+                    import torch.distributed as dist
+                    t = torch.tensor([us], dtype=torch.float64, device=self.device)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    us = float(t.item())
+                results.append((int(k), us))
+            best = min(results, key=lambda kv: kv[1])
+            if best[0] != 0 and best[1] > 0.97 * dict(results).get(0, float("inf")):
+                best = (0, dict(results)[0])  # (a partition has to pay clearly: it also takes the learner's stream priority away)
+            self.set_cu_split(best[0])
+        finally:
+            self.defer_join = dj
+        self.cu_tuning = {"main_stream_cu_mask_bits": best[0], "us_per_step": best[1],
+                          "candidates": [{"main_bits": k, "us_per_step": us} for k, us in results],
+                          "note": "acting / env / replay on mask bits [0, k), the update on [k, n_cu); 0 = unpartitioned"}
+        return self.cu_tuning
 
     def tune_learner_stream(self, steps: int = 10, margin: float = 0.9):
         """Keep the high-priority learner stream unless a NORMAL-priority one is clearly faster (step time below `margin` x): with
@@ -651,7 +731,12 @@ def bench_train(args, world, rank, device, n_envs=None):
     # this bench reports)
     prefill = int(getattr(args, "prefill_steps", 1000))
     tr.prefill_env(prefill)
-    stream_tuning = tr.tune_learner_stream() if tr.overlap and not shipped else None
+    stream_tuning = tr.tune_learner_stream() if tr.overlap and not shipped and os.environ.get("TVC_TUNE_STREAM", "1") != "0" else None
+    cu_tuning = None
+    if getattr(args, "cu_split", "auto") == "auto":
+        cu_tuning = tr.tune_cu_split() if not shipped else None
+    elif int(args.cu_split) > 0:
+        tr.set_cu_split(int(args.cu_split))
     tuning = None
     if int(getattr(args, "share_rows", -1)) < 0 and utd == 1 and not shipped and tr.share_cus and tr.overlap and tr.uses_rows_kernel():
         tuning = tr.tune_share_rows()  # measured split, identical on every rank (times are maximised over the ranks)
@@ -669,6 +754,7 @@ def bench_train(args, world, rank, device, n_envs=None):
                                                       if shipped else "SAC policy",
                                                       "reward_history_window": int(tr.env.cfg.distinct_window),
                                                       "env_prefill_steps": prefill,
+                                                      "cu_split": {"main_stream_cu_mask_bits": tr.cu_split, "tuning": cu_tuning},
                                                       "streams": {**stream_report(), "tuning": stream_tuning,
                                                                   "collective_runs_beside_acting": collective_runs_beside(
                                                                       torch.cuda.current_stream(device), tr._side, device)},
