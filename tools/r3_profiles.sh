@@ -53,6 +53,9 @@ run --workload physics --envs-per-gpu 65536 --steps 2000 --warmup 100
 run --workload physics --envs-per-gpu 4194304 --steps 100 --warmup 10
 } > $O/bench_matrix.md
 python tools/env_dr_bench.py > $O/env_dr_bench.jsonl 2>/dev/null
+python tools/env_ring_bench.py 4096 65536 1048576 2>/dev/null | grep envs > $O/env_ring_bench.txt
+{ echo "## tools/chain_bench.py: us per launch in a hipGraph chain of 64 dependent launches"; python tools/chain_bench.py 2>/dev/null | tail -1
+  for mnk in "512 256 256" "512 256 512" "512 512 512"; do echo; echo "## tools/gemm_stamps.py $mnk (library built with -DTVC_GEMM_STAMPS)"; python tools/gemm_stamps.py $mnk 2>/dev/null | grep -v "^ *$"; done; } > $O/gemm_stamps.md
 echo "--- act bench" > $O/act_bench.txt; python tools/act_bench.py 1024 4096 8192 12288 16384 32768 65536 2>/dev/null | grep -v "^ *$" >> $O/act_bench.txt
 cp gpurun_out/parity_summary.json $O/parity_summary.json 2>/dev/null
 ls $O

@@ -27,5 +27,5 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for k in range(200): fn(k)
 torch.cuda.synchronize()
 print(f"streams touched before: {nn} normal + {nh} high priority; GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES', 'default')}: "
-      f"{(time.perf_counter() - t0) / 200 * 1e3:.3f} ms/step at {n} envs; probe {r['extra']['sac']['streams']} (TVC_STREAM_PROBE={os.environ.get('TVC_STREAM_PROBE', '1')})", flush=True)
+      f"{(time.perf_counter() - t0) / 200 * 1e3:.3f} ms/step at {n} envs; tuning {r['extra']['sac']['learner_stream']}", flush=True)
 r["trainer"].close()

@@ -54,34 +54,3 @@ def max_over_ranks(x: float, device) -> float:
     t = torch.tensor([x], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
-
-
-def collective_runs_beside(main: "torch.cuda.Stream", side: "torch.cuda.Stream", device, group=None):
-    """Does an all-reduce issued from `side` make progress while `main` is busy?  None at world 1 / on a CPU backend.  PyTorch runs
-    NCCL (= RCCL) collectives on a pooled stream of its own; if that stream shares a hardware queue with the stream the acting pass is
-    issued from, every all-reduce of the update waits for the acting launch in front of it (tvc_ai_amd/streams.py).  Diagnostic only:
-    bench.py prints the answer; the remedy is more hardware queues (GPU_MAX_HW_QUEUES) or a fresh process group."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1 or dist.get_backend(group) != "nccl":
-        return None
-    from .streams import _spin
-    dev = torch.device(device)
-    big = torch.empty(1 << 26, device=dev)
-    tiny = torch.zeros(64, device=dev)
-    with torch.cuda.stream(side):
-        dist.all_reduce(tiny, group=group)  # communicator and stream exist
-    torch.cuda.synchronize(dev)
-    dist.barrier(group)
-    done_main, done_side = torch.cuda.Event(), torch.cuda.Event()
-    with torch.cuda.stream(main):
-        _spin(dev, big)
-        _spin(dev, big)
-        done_main.record(main)
-    with torch.cuda.stream(side):
-        dist.all_reduce(tiny, group=group)
-        done_side.record(side)
-    done_side.synchronize()
-    beside = not done_main.query()
-    torch.cuda.synchronize(dev)
-    flag = torch.tensor([1.0 if beside else 0.0], device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)  # one rank's collision stalls everyone
-    return bool(flag.item() > 0.5)

@@ -10,12 +10,10 @@ learner stream, or GPU_MAX_HW_QUEUES >= 8, never did).  So:
   * VecTrainer.tune_learner_stream() times a few steps with the high- and the normal-priority learner stream and keeps the faster
     (bench.py calls it at warm-up): whatever else shares the process, the collapse cannot survive into the measured steps."""
 import os
-import warnings
 
 import torch
 
 _cache = {}
-_rejected = []  # streams that shared a queue with the main stream: kept alive so that the pool moves on
 
 
 def _key(device):
@@ -23,59 +21,14 @@ def _key(device):
     return d.index if d.index is not None else torch.cuda.current_device()
 
 
-def _spin(device, x):
-    """~1 ms of work on the current stream"""
-    try:
-        torch.cuda._sleep(2_000_000)  # cycles of the shader clock (~2.4 GHz)
-    except Exception:  # no _sleep in this build: a chain of passes over a 256 MB tensor
-        for _ in range(16):
-            x.mul_(1.0)
-
-
-def runs_beside(main: "torch.cuda.Stream", side: "torch.cuda.Stream", device) -> bool:
-    """does work on `side` make progress while `main` is busy?  (False: the two share a hardware queue)"""
-    dev = torch.device(device)
-    big = torch.empty(1 << 26, device=dev)
-    tiny = torch.zeros(64, device=dev)
-    torch.cuda.synchronize(dev)
-    ok_votes = 0
-    for _ in range(2):
-        done_main, done_side = torch.cuda.Event(), torch.cuda.Event()
-        with torch.cuda.stream(main):
-            _spin(dev, big)
-            done_main.record(main)
-        with torch.cuda.stream(side):
-            tiny.add_(1.0)
-            done_side.record(side)
-        done_side.synchronize()
-        ok_votes += 0 if done_main.query() else 1
-        torch.cuda.synchronize(dev)
-    return ok_votes == 2
-
-
-def learner_stream(device, priority=None, tries: int = 12) -> "torch.cuda.Stream":
+def learner_stream(device, priority=None) -> "torch.cuda.Stream":
     """stream the SAC update runs on beside the acting pass (VecTrainer); high priority unless TVC_SIDE_PRIORITY / `priority` says
-    otherwise; one per (device, priority).  TVC_STREAM_PROBE=1 probes candidates against the CURRENT stream (diagnostic)."""
+    otherwise; one per (device, priority)"""
     prio = int(os.environ.get("TVC_SIDE_PRIORITY", "-1")) if priority is None else int(priority)
     k = ("learner", _key(device), prio)
-    if k in _cache:
-        return _cache[k]
-    dev = torch.device("cuda", k[1])
-    main = torch.cuda.current_stream(dev)
-    probe = os.environ.get("TVC_STREAM_PROBE", "0") != "0"
-    chosen = None
-    for _ in range(max(1, tries)):
-        s = torch.cuda.Stream(dev, priority=prio)
-        if not probe or runs_beside(main, s, dev):
-            chosen = s
-            break
-        _rejected.append(s)
-    if chosen is None:
-        warnings.warn("tvc_ai_amd: no stream found that runs beside the current stream (hardware queues oversubscribed?); the "
-                      "two-stream train step will be slow -- try GPU_MAX_HW_QUEUES=8")
-        chosen = torch.cuda.Stream(dev, priority=prio)
-    _cache[k] = chosen
-    return chosen
+    if k not in _cache:
+        _cache[k] = torch.cuda.Stream(torch.device("cuda", k[1]), priority=prio)
+    return _cache[k]
 
 
 def masked_stream(device, lo: int, hi: int) -> "torch.cuda.Stream":
@@ -111,8 +64,3 @@ def capture_stream(device) -> "torch.cuda.Stream":
     if k not in _cache:
         _cache[k] = torch.cuda.Stream(torch.device("cuda", k[1]))
     return _cache[k]
-
-
-def report() -> dict:
-    """what the probes found (bench.py prints it)"""
-    return {"learner_streams_rejected_by_probe": len(_rejected)}

@@ -15,11 +15,11 @@ import os
 
 import torch
 
-from .streams import capture_stream, learner_stream, masked_stream, report as stream_report
+from .streams import capture_stream, learner_stream, masked_stream
 
 from .agent import NativeSAC, ReplayBuffer, dropout_seed_of, sac_cfg
 from .env import VecRocketTVCEnv
-from .parallel import GradSync, broadcast_parameters, collective_runs_beside
+from .parallel import GradSync, broadcast_parameters
 
 
 class VecTrainer:
@@ -755,9 +755,7 @@ def bench_train(args, world, rank, device, n_envs=None):
                                                       "reward_history_window": int(tr.env.cfg.distinct_window),
                                                       "env_prefill_steps": prefill,
                                                       "cu_split": {"main_stream_cu_mask_bits": tr.cu_split, "tuning": cu_tuning},
-                                                      "streams": {**stream_report(), "tuning": stream_tuning,
-                                                                  "collective_runs_beside_acting": collective_runs_beside(
-                                                                      torch.cuda.current_stream(device), tr._side, device)},
+                                                      "learner_stream": stream_tuning,
                                                       "domain_randomisation": "off (shipped env)" if stage is None
                                                       else f"curriculum stage {stage} with the curriculum driver attached "
                                                            f"(device-side episode statistics): {env_over}"}}}
