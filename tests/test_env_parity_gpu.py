@@ -233,6 +233,36 @@ def test_exact_distinct_window_mode():
     env.close()
 
 
+def test_full_ring_distinct_count_stays_exact_through_evictions():
+    """The 1000-entry reward history FULL and wrapping (1300 steps): the incremental distinct count (a scan of the whole ring per step
+    that counts matches of the evicted and of the new value, tvc_env_device.h) against a brute-force count over the exported ring.
+    Zero-action envs repeat the same episode over and over (nominal env, auto-reset), so their windows are full of duplicates and
+    most evictions remove one copy of a value that is still present; the other envs draw random actions."""
+    n, steps = 96, 1300
+    rng = np.random.default_rng(11)
+    env = make_env(n, contact=1, auto_reset=1, distinct_window=1000)
+    env.reset()
+    acts = torch.from_numpy(rng.uniform(-1, 1, (steps, n, 2)).astype(np.float32)).cuda()
+    acts[:, : n // 2] = 0.0
+    acts[:, n // 2: 3 * n // 4] = acts[:, n // 2: 3 * n // 4].round()  # saturated actions: more repeated rewards
+    checked = 0
+    for t in range(steps):
+        env.step(acts[t])
+        if t in (998, 999, 1000, 1001, 1150, steps - 1):  # around the moment the ring fills, and after it wrapped
+            st = env.export_state()
+            aux, hist = st["aux"].cpu().numpy(), st["hist"].cpu().numpy()
+            hl = min(t + 1, 1000)
+            assert (aux[:, 4] == hl).all()
+            brute = np.array([len(set(hist[i, :hl].tolist())) for i in range(n)])
+            assert (aux[:, 6] == brute).all(), (t, np.nonzero(aux[:, 6] != brute)[0][:8], aux[:8, 6], brute[:8])
+            checked += 1
+    dup_frac = 1.0 - brute[: n // 2].mean() / 1000.0
+    assert dup_frac > 0.5, dup_frac  # the zero-action windows really are mostly duplicates
+    parity_log.record("full_ring_distinct_count", envs=n, steps=steps, checks=checked, duplicate_fraction_zero_action=float(dup_frac),
+                      min_distinct=int(brute.min()), max_distinct=int(brute.max()))
+    env.close()
+
+
 def test_domain_randomisation_parity():
     n = 192
     rng = np.random.default_rng(5)

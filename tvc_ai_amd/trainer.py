@@ -65,7 +65,7 @@ class VecTrainer:
         self.stream_tuning = None
         # the learner's stream: high HIP priority + raised wave priority inside its kernels (TVC_LEARNER_PRIO): -4 % on the step at
         # 2 and 4 updates per step, the update ends ~0.2 ms earlier at 1 (tools/ab_prio.sh)
-        self._side = learner_stream(self.device)  # (one per process and device: streams.py)
+        self._side = self._learner = learner_stream(self.device)  # (one per process and device: streams.py)
         self._main = None        # set_cu_split(): the step's own (CU-masked) stream instead of the caller's current stream
         self.cu_split = 0
         self.cu_tuning = None
@@ -191,7 +191,8 @@ class VecTrainer:
         cur, nxt = self.obs[self.cur], self.obs[1 - self.cur]
         self.eps_act.normal_()
         raw = self.act_raw if self.safety is not None else self.act
-        share = self.share_cus and self._snapshot and self.share_rows > 0
+        # (with a CU partition the acting kernel has its slice of the chip to itself: exclusive form)
+        share = self.share_cus and self._snapshot and self.share_rows > 0 and self._main is None
         if self.hier is not None:
             self.u_goal.uniform_()
             # (the never-trained hierarchy has no snapshot to read; the update runs beside it)
@@ -245,7 +246,7 @@ class VecTrainer:
         k = int(main_bits)
         if k <= 0:
             self._main, self.cu_split = None, 0
-            self._side = learner_stream(self.device)
+            self._side = self._learner
             return
         if k % 8 or not (8 <= k <= n_cu - 8):
             raise ValueError(f"set_cu_split: a multiple of 8 in [8, {n_cu - 8}] (8 mask bits = one CU per XCD)")
@@ -258,10 +259,16 @@ class VecTrainer:
         if self._main is None or torch.cuda.is_current_stream_capturing():
             return fn()
         caller = torch.cuda.current_stream(self.device)
-        self._main.wait_stream(caller)
+        # hipExtStreamCreateWithCUMask makes BLOCKING streams: the legacy default stream already orders itself against them (and an
+        # explicit wait enqueued on it would drag the learner's stream into that ordering every step: 1.6 instead of 0.65 ms per
+        # step at 4 096 envs).  Only a caller on a stream of its own needs the explicit edges.
+        explicit = caller.cuda_stream != 0
+        if explicit:
+            self._main.wait_stream(caller)
         with torch.cuda.stream(self._main):
             out = fn()
-        caller.wait_stream(self._main)
+        if explicit:
+            caller.wait_stream(self._main)
         return out
 
     def step(self, learn: bool = True):
@@ -530,22 +537,24 @@ class VecTrainer:
                                      "choice; times are max over ranks"}
         return self.share_tuning
 
-    def tune_cu_split(self, candidates=(0, 96, 128), steps: int = 20):
+    def tune_cu_split(self, candidates=(0, 96, 128, 160), steps: int = 30):
         """Choose the CU partition of the two streams (set_cu_split) from measured step times, like tune_share_rows (real train
-        steps in the deferred-join regime, max over ranks, every rank takes the same decision).  Only below 12 288 envs, where the
-        acting kernel needs at most two workgroups per CU of half the chip and the update is the critical path."""
-        if not self.overlap or self.hier is not None or self.n >= 12288 or not self.uses_rows_kernel():
+        steps in the deferred-join regime, max over ranks, every rank takes the same decision).  Only up to 16 384 envs, where the
+        acting kernel's 256 - 512 workgroups fit a slice of the chip at two per CU and the update is the critical path."""
+        if not self.overlap or self.hier is not None or self.n > 16384 or not self.uses_rows_kernel():
             return None
         while self.steps < 2:
+            self.step(True)
+        for _ in range(10):  # (the first candidate would otherwise pay for whatever the previous phase left cold)
             self.step(True)
         dj = self.defer_join
         self.defer_join = True
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        results = []
+        seen = {}
         try:
-            for k in candidates:
+            for k in list(candidates) * 2:  # two passes, the minimum counts: a one-off stall (seen: ~20 ms) must not decide
                 self.set_cu_split(int(k))
-                for _ in range(3):
+                for _ in range(6):
                     self.step(True)
                 torch.cuda.synchronize(self.device)
                 e0.record()
@@ -560,7 +569,8 @@ class VecTrainer:
                     t = torch.tensor([us], dtype=torch.float64, device=self.device)
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                     us = float(t.item())
-                results.append((int(k), us))
+                seen[int(k)] = min(us, seen.get(int(k), float("inf")))
+            results = [(int(k), seen[int(k)]) for k in candidates]
             best = min(results, key=lambda kv: kv[1])
             if best[0] != 0 and best[1] > 0.97 * dict(results).get(0, float("inf")):
                 best = (0, dict(results)[0])  # (a partition has to pay clearly: it also takes the learner's stream priority away)
@@ -604,7 +614,7 @@ class VecTrainer:
             res[name] = us
         pick = "normal" if res["normal"] < margin * res["high"] else "high"
         torch.cuda.synchronize(self.device)
-        self._side = dict(cands)[pick]
+        self._side = self._learner = dict(cands)[pick]
         self.stream_tuning = {"learner_stream_priority": pick, "us_per_step": res}
         return self.stream_tuning
 
@@ -732,14 +742,14 @@ def bench_train(args, world, rank, device, n_envs=None):
     prefill = int(getattr(args, "prefill_steps", 1000))
     tr.prefill_env(prefill)
     stream_tuning = tr.tune_learner_stream() if tr.overlap and not shipped and os.environ.get("TVC_TUNE_STREAM", "1") != "0" else None
-    cu_tuning = None
+    tuning = None
+    if int(getattr(args, "share_rows", -1)) < 0 and utd == 1 and not shipped and tr.share_cus and tr.overlap and tr.uses_rows_kernel():
+        tuning = tr.tune_share_rows()  # measured split, identical on every rank (times are maximised over the ranks)
+    cu_tuning = None  # (after the split: the unpartitioned candidate is then the best unpartitioned schedule)
     if getattr(args, "cu_split", "auto") == "auto":
         cu_tuning = tr.tune_cu_split() if not shipped else None
     elif int(args.cu_split) > 0:
         tr.set_cu_split(int(args.cu_split))
-    tuning = None
-    if int(getattr(args, "share_rows", -1)) < 0 and utd == 1 and not shipped and tr.share_cus and tr.overlap and tr.uses_rows_kernel():
-        tuning = tr.tune_share_rows()  # measured split, identical on every rank (times are maximised over the ranks)
     fam = "reference shapes (seq-len-1 transformer actor 2.26M trainable params, 512/256 GELU+LN critics)" if family == 0 \
         else "256x256 ReLU MLP actor/critics"
     return {"step_fn": lambda k: tr.step(True), "env": tr.env, "trainer": tr,
