@@ -248,13 +248,21 @@ int tvc_sac_set_adam_steps(tvc_sac* sac, const int32_t in[2]);
 int tvc_sac_get_act_counter(tvc_sac* sac, int32_t* out);
 int tvc_sac_set_act_counter(tvc_sac* sac, int32_t value);
 
+/* Packs the split-operand weight stream of the acting net (tvc_sac_act flags bit 4) from the current folded weights; from then on
+ * every policy update re-packs it and every snapshot copies it.  tvc_sac_act does this itself on first use; call it explicitly
+ * before a loop whose updates run on another stream.  Idempotent. */
+int tvc_sac_enable_x3(tvc_sac* sac, void* stream);
+
 /* Policy part of get_action (agent/...:765-789) for n rows: mean/log_std (clamped to [-20,2]) and
  * action = clamp(mean + exp(log_std) * eps, -1, 1); eps_dev NULL = deterministic (action = clamp(mean)).
  * flags bit 0: do not clamp (the safety layer sees the raw sample, agent/...:780-789); bit 1: act with the snapshot;
  * bit 2: share the CUs -- the one-launch acting kernel (n >= 12 288 rows, reference shapes) then occupies half of each CU's
  * registers instead of all of them, so that kernels on other streams (a SAC update) run beside it instead of after it;
  * bit 3: act in TRAIN mode like the reference's get_action (no .eval() anywhere, agent/...:765): Dropout active at every site of
- * the policy with fresh masks per call (needs family 0 and dropout_p > 0; per-layer kernels, attention not folded).
+ * the policy with fresh masks per call (needs family 0 and dropout_p > 0; per-layer kernels, attention not folded);
+ * bit 4: split-operand arithmetic for the one-launch kernel (n >= 16 384 rows, reference shapes; ignored otherwise): every Linear on the
+ * bf16 matrix pipe with both operands written as three bf16 terms and six products accumulated in fp32 -- the same fp32 result to
+ * rounding (error against an fp64 sum equal to the f32-input MFMA's, tests/test_acting_x3_gpu.py) at 6 / 16 of its MFMA cycles.
  * obs_dev float[n,obs]; act_dev float[n,A]; mean_dev / logstd_dev float[n,A] or NULL. */
 int tvc_sac_act(tvc_sac* sac, const float* obs_dev, int32_t n, const float* eps_dev, float* act_dev, float* mean_dev,
                 float* logstd_dev, int32_t flags, void* stream);

@@ -1,0 +1,95 @@
+"""Split-operand acting kernel (tvc_actor_x3.h, tvc_sac_act flags bit 4): every Linear of the policy on the bf16 matrix pipe with both
+operands written as three bf16 terms, six products, fp32 accumulate.
+
+What is checked: (1) against the fp64 evaluation of the restatement (oracle/sac_torch.actor_forward on float64 tensors) the kernel is
+as close as the exact f32-MFMA kernel -- max error <= 1.5 x the f32 kernel's + 2e-6, and within the 3e-4 bar every acting test
+uses; (2) the snapshot / share-CUs forms are bit-equal to the plain call; (3) a policy update re-packs the stream."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sac_torch as st
+
+pytestmark = pytest.mark.gpu
+
+
+def cuda(*xs):
+    return [torch.as_tensor(x).cuda().contiguous() for x in xs]
+
+
+def _perturb(sac):
+    for name, _, rows, cols in sac.table:  # non-trivial norms / biases so that every epilogue term is exercised
+        if name.startswith("policy.") and cols == 1:
+            sac.view(name).add_(0.1 * torch.randn(rows, device="cuda", generator=torch.Generator(device="cuda").manual_seed(rows)))
+    sac.sync_derived()
+
+
+def _ref64(P, obs):
+    P64 = {k: v.double() for k, v in P.items()}
+    with torch.no_grad():
+        return st.actor_forward(P64, obs.double(), batch_pe=False)
+
+
+@pytest.mark.parametrize("n,use_se", [(65536, 0), (65536 - 37, 0), (40000 + 21, 0), (40005, 1)])
+def test_x3_acting_is_as_close_to_fp64_as_the_f32_kernel(n, use_se):
+    from tvc_ai_amd.agent import NativeSAC, sac_cfg
+    torch.set_num_threads(8)
+    obs_dim = 14 if use_se else 10
+    sac = NativeSAC(sac_cfg(0, obs_dim=obs_dim, batch_size=64, max_act_rows=65536, use_se=use_se), seed=13)
+    _perturb(sac)
+    P = sac.export_reference_state("policy")
+    if use_se:  # (the reference-keyed export covers the SAC policy's tensors; the SE block belongs to the hierarchical policy)
+        for key in ("se_block.fc1.weight", "se_block.fc1.bias", "se_block.fc2.weight", "se_block.fc2.bias"):
+            P[key] = sac.view("policy." + key).detach().cpu().clone()
+    g = torch.Generator().manual_seed(n)
+    obs = torch.randn(n, obs_dim, generator=g) * 0.5
+    eps = torch.randn(n, 2, generator=g)
+    o, e = cuda(obs, eps)
+    a32, m32, l32 = [t.clone() for t in sac.act(o, e)]
+    a3, m3, l3 = [t.clone() for t in sac.act(o, e, x3=True)]
+    assert torch.isfinite(m3).all() and torch.isfinite(l3).all()
+    pick = torch.cat([torch.arange(0, 300), torch.randint(0, n, (1200,), generator=g), torch.arange(n - 300, n)])
+    m_ref, ls_ref = _ref64(P, obs[pick])
+    def err(m, ls):
+        return max(float((m.cpu()[pick].double() - m_ref).abs().max()), float((ls.cpu()[pick].double() - ls_ref).abs().max()))
+    e32, e3 = err(m32, l32), err(m3, l3)
+    from tests import parity_log
+    parity_log.record(f"acting_x3_vs_fp64_n{n}_se{use_se}", max_err_x3=e3, max_err_f32_mfma=e32,
+                      max_abs_diff_x3_f32=float((m3 - m32).abs().max()))
+    assert e3 <= 3e-4, e3
+    assert e3 <= 1.5 * e32 + 2e-6, (e3, e32)
+    a_ref = (m_ref + torch.exp(ls_ref) * eps[pick].double()).clamp(-1, 1)
+    np.testing.assert_allclose(a3.cpu()[pick].double().numpy(), a_ref.numpy(), atol=1e-3, rtol=0)
+    # all rows against the f32 kernel (both are fp32-exact to rounding: a few 1e-6)
+    assert float((m3 - m32).abs().max()) <= 5e-5 and float((l3 - l32).abs().max()) <= 5e-5
+    # snapshot + share-CUs forms: same kernel, same tile stream -> bit-equal
+    sac.snapshot_policy()
+    k = (n // 2) // 64 * 64
+    outs = tuple(torch.empty(n, 2, device="cuda") for _ in range(3))
+    sac.act(o[:k], e[:k], out=tuple(t[:k] for t in outs), snapshot=True, share_cus=True, x3=True)
+    sac.act(o[k:], e[k:], out=tuple(t[k:] for t in outs), snapshot=True, x3=True)
+    assert torch.equal(outs[0], a3) and torch.equal(outs[1], m3) and torch.equal(outs[2], l3)
+    sac.close()
+
+
+def test_x3_stream_is_repacked_by_a_policy_update():
+    from tvc_ai_amd.agent import NativeSAC, sac_cfg
+    n, B = 16384, 64
+    sac = NativeSAC(sac_cfg(0, batch_size=B, max_act_rows=n, dropout_p=0.0), seed=5)
+    g = torch.Generator().manual_seed(1)
+    obs = torch.randn(n, 10, generator=g) * 0.5
+    o, = cuda(obs)
+    sac.enable_x3()
+    m_before = sac.act(o, None, x3=True)[1].clone()
+    s, s2 = torch.randn(B, 10, generator=g), torch.randn(B, 10, generator=g)
+    a, r, d = torch.rand(B, 2, generator=g) * 2 - 1, torch.randn(B, generator=g), torch.zeros(B)
+    e1, e2 = torch.randn(B, 2, generator=g), torch.randn(B, 2, generator=g)
+    for _ in range(3):
+        sac.update(*cuda(s, a, r, s2, d, e1, e2))
+    P = sac.export_reference_state("policy")
+    m3 = sac.act(o, None, x3=True)[1]
+    assert float((m3 - m_before).abs().max()) > 1e-4  # the policy moved
+    pick = torch.arange(0, n, 37)
+    m_ref, _ = _ref64(P, obs[pick])
+    assert float((m3.cpu()[pick].double() - m_ref).abs().max()) <= 3e-4
+    sac.close()

@@ -89,6 +89,7 @@ SIGNATURES.update({
     "tvc_sac_set_act_counter": (C.c_int, [_VP, C.c_int32]),
     "tvc_sac_sync_derived": (C.c_int, [_VP, _VP]),
     "tvc_sac_snapshot_policy": (C.c_int, [_VP, _VP]),
+    "tvc_sac_enable_x3": (C.c_int, [_VP, _VP]),
     "tvc_sac_act": (C.c_int, [_VP, _VP, C.c_int32, _VP, _VP, _VP, _VP, C.c_int32, _VP]),
     "tvc_debug_rows_clock": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.POINTER(C.c_double), _VP]),
     "tvc_debug_rows_stamps": (C.c_int, [_VP, _VP, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint64), _VP]),

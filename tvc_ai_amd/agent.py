@@ -240,20 +240,26 @@ class NativeSAC:
         nat.check(self.L.tvc_sac_snapshot_policy(self._h, self._stream()))
 
     def act(self, obs: torch.Tensor, eps: Optional[torch.Tensor] = None, out=None, clamp: bool = True, snapshot: bool = False,
-            share_cus: bool = False, train_mode: bool = False):
+            share_cus: bool = False, train_mode: bool = False, x3: bool = False):
         """-> (action[n,A] clamped to [-1,1] unless clamp=False, mean, log_std); eps None = deterministic.
         snapshot=True acts with the parameters of the last snapshot_policy() instead of the live ones; share_cus=True leaves
         half of every CU to other streams (tvc_sac_act flags bit 2); train_mode=True keeps Dropout active while acting, as the
-        reference does (it never calls .eval(), agent/...:765): flags bit 3, per-layer kernels, fresh masks every call."""
+        reference does (it never calls .eval(), agent/...:765): flags bit 3, per-layer kernels, fresh masks every call;
+        x3=True runs the one-launch kernel (n >= 16 384 rows) on the bf16 matrix pipe with three-term split operands (flags bit 4:
+        fp32-exact, tvc_actor_x3.h)."""
         n, A = obs.shape[0], self.cfg.act_dim
         assert obs.dtype == torch.float32 and obs.is_contiguous() and obs.shape[1] == self.cfg.obs_dim
         if out is None:
             out = tuple(torch.empty((n, A), dtype=torch.float32, device=self.device) for _ in range(3))
         act, mean, ls = out
         nat.check(self.L.tvc_sac_act(self._h, obs.data_ptr(), n, nat.ptr(eps), act.data_ptr(), mean.data_ptr(), ls.data_ptr(),
-                                     (0 if clamp else 1) | (2 if snapshot else 0) | (4 if share_cus else 0) | (8 if train_mode else 0),
+                                     (0 if clamp else 1) | (2 if snapshot else 0) | (4 if share_cus else 0) | (8 if train_mode else 0) | (16 if x3 else 0),
                                      self._stream()))
         return act, mean, ls
+
+    def enable_x3(self):
+        """Packs the split-operand weight stream now (tvc_sac_enable_x3): call before a loop whose updates run on another stream."""
+        nat.check(self.L.tvc_sac_enable_x3(self._h, self._stream()))
 
     def update(self, s, a, r, s2, d, eps_next, eps_new, all_reduce=None, grad_scale: float = 1.0):
         """One _update_sac.  all_reduce(tensor) is called on the critic and then on the actor gradient

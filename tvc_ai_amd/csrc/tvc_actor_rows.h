@@ -440,13 +440,65 @@ __device__ __forceinline__ void pack_head(const HeadPack& hp, float (*red)[4][25
         if (which == 1 && hp.tail_t) hp.tail_t[2048 + o] = o < hp.n_out ? hp.b8[o] : 0.0f;
     }
 }
-// two streams per launch: the acting net (attention and embedding folded) and, when train-mode acting is available, the net as trained
+// ------------------------------------------------------------------ packing of the split-operand stream (tvc_actor_x3.h)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int X3_TRI = 8;                    // split-operand stream (tvc_actor_x3.h): triples per tile
+constexpr int X3_TILE_BYTES = X3_TRI * 3072;  // 24 KB
+// One descriptor per 24 KB tile: triples g0 .. g0 + 7 of a pass over NT n-tiles (triple g: k-block g / NT, n-tile g % NT) of the
+// matrix at `src` (float offset of W[n0][0], row stride ld); input feature of k-slot (kb, q, c) = k0 + 32 kb + 16 (c / 4) + 4 q + (c % 4),
+// zero at and beyond kvalid; rows at and beyond nvalid (relative to n0) are zero (the 16-row SE matrix).  kvalid = 0: an all-zero tile.
+struct PackTile3 { long src; int ld, k0, kvalid, nvalid, g0, NT, from_ov; };
+__device__ __forceinline__ unsigned x3_rne_bits(float x) {  // the bf16 nearest to x, in the upper half of the word
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u & 0xFFFF0000u;
+}
+__device__ __forceinline__ void pack_x3_tile(const PackTile3& t, const float* __restrict__ P, const float* __restrict__ OV,
+                                             u32x4_t* __restrict__ out) {
+    const float* base = (t.from_ov ? OV : P) + t.src;
+    for (int it = threadIdx.x; it < X3_TRI * 64; it += 256) {  // (triple j, lane): 8 weights -> three 16-byte fragments pieces
+        const int j = it >> 6, lane = it & 63, n = lane & 15, q = lane >> 4;
+        const int g = t.g0 + j, kb = g / t.NT, nt = g % t.NT;
+        const int nrow = 16 * nt + n;
+        const float* r = base + (long)nrow * t.ld;
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int k = t.k0 + 32 * kb + 16 * (c >> 2) + 4 * q + (c & 3);
+            float w = 0.0f;
+            if (k < t.kvalid && nrow < t.nvalid) w = r[k];
+            h[c] = x3_rne_bits(w);
+            const float r1 = w - __uint_as_float(h[c]);
+            m[c] = x3_rne_bits(r1);
+            const float r2 = r1 - __uint_as_float(m[c]);
+            l[c] = x3_rne_bits(r2);
+        }
+        u32x4_t H, M, L;
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            H[pp] = (h[2 * pp] >> 16) | h[2 * pp + 1];
+            M[pp] = (m[2 * pp] >> 16) | m[2 * pp + 1];
+            L[pp] = (l[2 * pp] >> 16) | l[2 * pp + 1];
+        }
+        out[(3 * j + 0) * 64 + lane] = H;
+        out[(3 * j + 1) * 64 + lane] = M;
+        out[(3 * j + 2) * 64 + lane] = L;
+    }
+}
+struct PackSet3 { const PackTile3* tiles; int n_tiles; char* out; };
+// up to three streams per launch: the acting net (attention and embedding folded), when train-mode acting is live the net as trained,
+// and when split-operand acting is live the folded net again as bf16 triples
 __global__ void __launch_bounds__(256) pack_actor_kernel(const float* __restrict__ P, const float* __restrict__ OV, PackSet s0, PackSet s1,
-                                                         HeadPack hp, Ticks tk) {
+                                                         HeadPack hp, Ticks tk, PackSet3 s3) {
     __shared__ float red[2][4][256];
     int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int n0 = s0.n_tiles + s0.n_vecs, n1 = s1.n_tiles + s1.n_vecs;
+    if (b > n0 + n1) {  // behind the head's workgroup: the split-operand stream (when it is live), one 24 KB tile per workgroup
+        const int i = b - (n0 + n1 + 1);
+        pack_x3_tile(s3.tiles[i], P, OV, reinterpret_cast<u32x4_t*>(s3.out + (size_t)i * X3_TILE_BYTES));
+        return;
+    }
     if (b == n0 + n1) {  // last workgroup: the folded output head (+ the riders of this launch)
         if (tid == 0) run_ticks(tk);
         pack_head(hp, red);

@@ -21,6 +21,7 @@
 #include "tvc_nn_kernels.h"
 #include "tvc_actor_rows.h"
 #include "tvc_actor_split.h"
+#include "tvc_actor_x3.h"
 
 using namespace tvcnn;
 
@@ -965,6 +966,12 @@ struct tvc_sac {
     float *tpack = nullptr, *snap_tpack = nullptr;  // [trows_tiles * 4096 tile floats | train vector section]
     PackTile* d_tptiles = nullptr;
     PackVec* d_tpvecs = nullptr;
+    // ... and the folded net as bf16 triples for the split-operand acting kernel (tvc_actor_x3.h, tvc_sac_act flags bit 4): packed,
+    // re-packed and snapshotted only once that kernel has been asked for
+    bool x3_live = false, x3_attr_set = false;
+    int x3_tiles = 0;
+    char *xpack = nullptr, *snap_xpack = nullptr;  // [x3_tiles * 24 KB]; the vector section is `pack`'s
+    PackTile3* d_xtiles = nullptr;
     float* tq = nullptr;                          // [2, B]: output of the target critics (read by q_loss_kernel)
     bool tick_pending = false;                    // the critics' Adam clock is one step behind: its advance rides on the next
                                                   // launch of the chain (tvc_sac_actor_grads), or is flushed by whoever needs it
@@ -1048,6 +1055,37 @@ static void rows_tables(const tvc_sac_cfg& c, const NetDef& actor, const FoldInf
     for (int half = 0; half < 2; ++half) pass(off("policy_head.4.weight"), 512, 256 * half, 0, 32, 512, 0);
     vec(off("policy_head.4.bias"), tv + 2048, 512, 0);
     // policy_head.6 (LayerNorm) and policy_head.8 (output Linear) enter the tail through pack_head_kernel, already folded
+}
+
+// The same net as the split-operand stream (tvc_actor_x3.h): per pass NT n-tiles x KB k-blocks, 8 triples per tile.
+static void rows_tables_x3(const tvc_sac_cfg& c, const NetDef& actor, const FoldInfo& f, std::vector<PackTile3>& tiles) {
+    auto off = [&](const std::string& name) -> long {
+        for (const TensorInfo& t : actor.tensors)
+            if (t.name == name) return t.off;
+        return -1;
+    };
+    const int d = 256;
+    const long ostride = (long)d * d + d;
+    auto pass = [&](long src, int ld, int n0, int k0, int NT, int KB, int kvalid, int nvalid, int from_ov) {
+        for (int g0 = 0; g0 < NT * KB; g0 += X3_TRI)
+            tiles.push_back(PackTile3{src < 0 ? -1 : src + (long)n0 * ld, ld, k0, kvalid, nvalid, g0, NT, from_ov});
+    };
+    for (int l = 0; l < c.n_layers; ++l) {
+        const std::string p = "layers." + std::to_string(l) + ".";
+        if (l == 0) pass(f.e_off, f.obs, 0, 0, 16, 1, f.obs, d, 1);   // W' [256][obs]: one k-block, 16 triples = two tiles
+        else pass(l * ostride, d, 0, 0, 16, 8, d, d, 1);               // W_ov of layer l
+        for (int quarter = 0; quarter < 4; ++quarter) {
+            pass(off(p + "linear1.weight"), d, 128 * quarter, 0, 8, 8, d, 128, 0);        // hidden units [128 quarter, +128) <- x
+            pass(off(p + "linear2.weight"), 512, 0, 128 * quarter, 16, 4, 512, d, 0);    // out += W2[:, hidden quarter] h
+        }
+    }
+    if (c.use_se) {
+        pass(off("se_block.fc1.weight"), d, 0, 0, 1, 8, d, 16, 0);   // [16][256]: one tile
+        tiles.push_back(PackTile3{0, 1, 0, 0, 0, 0, 1, 0});          // + an all-zero tile (ring parity)
+        pass(off("se_block.fc2.weight"), 16, 0, 0, 16, 1, 16, d, 0); // [256][16]: two tiles
+    }
+    for (int half = 0; half < 2; ++half) pass(off("policy_head.0.weight"), d, 256 * half, 0, 16, 8, d, d, 0);
+    for (int half = 0; half < 2; ++half) pass(off("policy_head.4.weight"), 512, 256 * half, 0, 16, 16, 512, d, 0);
 }
 
 // Train-mode stream: embedding (one tile), then per encoder layer v_proj (16 tiles), out_proj (16), the FFN as in rows_tables(),
@@ -1243,6 +1281,13 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
         h->pack_floats = (long)h->rows_tiles * 4096 + (long)cfg->n_layers * AR_LAYER_VEC + AR_TAIL_VEC + (cfg->use_se ? AR_SE_VEC : 0);
         bytes += 2 * h->pack_floats * 4 + ptiles.size() * sizeof(PackTile) + pvecs.size() * sizeof(PackVec) + 2048;
     }
+    std::vector<PackTile3> xtiles;
+    if (h->rows_ok) {
+        rows_tables_x3(*cfg, h->actor, h->fold, xtiles);
+        for (const PackTile3& t : xtiles) h->rows_ok = h->rows_ok && t.src >= 0;
+        h->x3_tiles = (int)xtiles.size();
+        bytes += 2L * h->x3_tiles * X3_TILE_BYTES + xtiles.size() * sizeof(PackTile3) + 2048;
+    }
     std::vector<PackTile> tptiles;
     std::vector<PackVec> tpvecs;
     h->train_rows_ok = h->rows_ok && want_dctx && !cfg->use_se;
@@ -1290,6 +1335,9 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
         h->snap_pack = (float*)carve(p, h->pack_floats * 4);
         h->d_ptiles = (PackTile*)carve(p, ptiles.size() * sizeof(PackTile));
         h->d_pvecs = (PackVec*)carve(p, pvecs.size() * sizeof(PackVec));
+        h->xpack = carve(p, (long)h->x3_tiles * X3_TILE_BYTES);
+        h->snap_xpack = carve(p, (long)h->x3_tiles * X3_TILE_BYTES);
+        h->d_xtiles = (PackTile3*)carve(p, xtiles.size() * sizeof(PackTile3));
     }
     if (h->train_rows_ok) {
         h->tpack = (float*)carve(p, h->tpack_floats * 4);
@@ -1318,6 +1366,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     if (h->rows_ok) {
         he = hipMemcpy(h->d_ptiles, ptiles.data(), ptiles.size() * sizeof(PackTile), hipMemcpyHostToDevice);
         if (he == hipSuccess) he = hipMemcpy(h->d_pvecs, pvecs.data(), pvecs.size() * sizeof(PackVec), hipMemcpyHostToDevice);
+        if (he == hipSuccess) he = hipMemcpy(h->d_xtiles, xtiles.data(), xtiles.size() * sizeof(PackTile3), hipMemcpyHostToDevice);
         if (he == hipSuccess && h->train_rows_ok) {
             he = hipMemcpy(h->d_tptiles, tptiles.data(), tptiles.size() * sizeof(PackTile), hipMemcpyHostToDevice);
             if (he == hipSuccess) he = hipMemcpy(h->d_tpvecs, tpvecs.data(), tpvecs.size() * sizeof(PackVec), hipMemcpyHostToDevice);
@@ -1348,6 +1397,29 @@ void tvc_sac_destroy(tvc_sac* h) {
     delete h;
 }
 
+// Split-operand acting stream (tvc_actor_x3.h): packed from the folded weights the last update left, then re-packed by every policy
+// update and copied by every snapshot.  Idempotent; stream-ordered (call it where no update runs on another stream).
+static int x3_make_live(tvc_sac* h, hipStream_t st) {
+    if (h->x3_live) return 0;
+    if (!h->rows_ok) return tvc::set_error(TVC_EINVAL, "split-operand acting needs the one-launch acting path (family 0 reference shapes)");
+    h->x3_live = true;
+    const float* P = h->P_actor();
+    HeadPack hp{P + h->head_off[0], P + h->head_off[1], P + h->head_off[2], P + h->head_off[3], 2 * h->cfg.act_dim,
+                h->pack + (long)h->rows_tiles * 4096 + (long)h->cfg.n_layers * AR_LAYER_VEC, nullptr};
+    PackSet none{nullptr, 0, nullptr, 0, nullptr, nullptr};
+    hipLaunchKernelGGL(pack_actor_kernel, dim3(1 + h->x3_tiles), dim3(256), 0, st, P, h->ov, none, none, hp,
+                       Ticks{nullptr, 0.f, 0.f, nullptr}, PackSet3{h->d_xtiles, h->x3_tiles, h->xpack});
+    // (a snapshot taken before this stream existed holds the same parameters unless an update ran in between)
+    TVC_HIP_CHECK(hipMemcpyAsync(h->snap_xpack, h->xpack, (size_t)h->x3_tiles * X3_TILE_BYTES, hipMemcpyDeviceToDevice, st));
+    TVC_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int tvc_sac_enable_x3(tvc_sac* h, void* stream) {
+    if (!h) return tvc::set_error(TVC_EINVAL, "null argument");
+    TVC_HIP_CHECK(hipSetDevice(h->device));
+    return x3_make_live(h, (hipStream_t)stream);
+}
+
 int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float* act, float* mean, float* logstd, int32_t flags,
                 void* stream) {
     if (!h || !obs || !act) return tvc::set_error(TVC_EINVAL, "null argument");
@@ -1374,7 +1446,7 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
                 PackSet s1{h->d_tptiles, h->trows_tiles, h->d_tpvecs, h->trows_vecs, reinterpret_cast<float4*>(h->tpack),
                            h->tpack + (long)h->trows_tiles * 4096};
                 hipLaunchKernelGGL(pack_actor_kernel, dim3(s1.n_tiles + s1.n_vecs + 1), dim3(256), 0, st, P, h->ov, none, s1, hp,
-                                   Ticks{nullptr, 0.f, 0.f, nullptr});
+                                   Ticks{nullptr, 0.f, 0.f, nullptr}, PackSet3{nullptr, 0, nullptr});
                 // (the snapshot, if one is being read, was taken before this stream existed: it holds the same parameters)
                 TVC_HIP_CHECK(hipMemcpyAsync(h->snap_tpack, h->tpack, h->tpack_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
             }
@@ -1410,6 +1482,28 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
                     nullptr, &dc);
         hipLaunchKernelGGL(sample_action_kernel, dim3((n * A + 255) / 256), dim3(256), 0, st, h->dctx.Y.back(), eps, act, mean, logstd,
                            n, A, (flags & 1) ? 0 : 1, Ticks{nullptr, 0.f, 0.f, h->act_ctr});  // ... and advances the call counter
+        TVC_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    if ((flags & 16) && h->rows_ok && n >= rows_min_rows() && g_force_variant == 0) {
+        // the whole pass as one launch on the bf16 matrix pipe, operands split in three bf16 terms, fp32-exact (tvc_actor_x3.h)
+        if (int e = x3_make_live(h, st)) return e;
+        const float* pk = snap ? h->snap_pack : h->pack;
+        ActRowsArgs a{};
+        a.obs = obs; a.eps = eps; a.act = act; a.mean = mean; a.logstd = logstd;
+        a.tiles = reinterpret_cast<const float4*>(snap ? h->snap_xpack : h->xpack); a.vec = pk + (long)h->rows_tiles * 4096;
+        a.M = n; a.obs_dim = h->cfg.obs_dim; a.A = A; a.clamp_act = (flags & 1) ? 0 : 1;
+        a.n_layers = h->cfg.n_layers; a.n_tiles = h->x3_tiles; a.stamps = h->rows_stamps; a.use_se = h->cfg.use_se;
+        size_t dyn_lds = 0;
+        if (flags & 4) {  // "share the CUs": 48 KB static + 64 KB unused dynamic LDS -> one workgroup per CU instead of two
+            if (!h->x3_attr_set) {
+                TVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(actor_x3_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+                h->x3_attr_set = true;
+            }
+            dyn_lds = 65536;
+        }
+        hipLaunchKernelGGL(actor_x3_kernel, dim3((n + 16 * X3_NW - 1) / (16 * X3_NW)), dim3(64 * X3_NW), dyn_lds, st, a);
         TVC_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -1482,7 +1576,7 @@ static int rows_probe(tvc_sac* h, const float* obs, int32_t n, int32_t launches,
     if (hipMalloc((void**)&act, (size_t)n * A * sizeof(float)) != hipSuccess) { (void)hipFree(st); return tvc::set_error(TVC_ENOMEM, "hipMalloc failed"); }
     h->rows_stamps = st;
     int rc = 0;
-    for (int i = 0; i < launches && rc == 0; ++i) rc = tvc_sac_act(h, obs, n, nullptr, act, nullptr, nullptr, flags & 4, stream);
+    for (int i = 0; i < launches && rc == 0; ++i) rc = tvc_sac_act(h, obs, n, nullptr, act, nullptr, nullptr, flags & (4 | 16), stream);
     h->rows_stamps = nullptr;
     hipError_t he = hipStreamSynchronize((hipStream_t)stream);
     v.assign((size_t)nwg * AR_STAMPS, 0);
@@ -1696,8 +1790,9 @@ static void refresh_folded(tvc_sac* h, hipStream_t st, AdamClock* tick) {
         if (!tl) hp.tail_t = nullptr;
         PackSet s1{h->d_tptiles, tl ? h->trows_tiles : 0, h->d_tpvecs, tl ? h->trows_vecs : 0,
                    reinterpret_cast<float4*>(h->tpack), tl ? h->tpack + (long)h->trows_tiles * 4096 : nullptr};
-        hipLaunchKernelGGL(pack_actor_kernel, dim3(s0.n_tiles + s0.n_vecs + s1.n_tiles + s1.n_vecs + 1), dim3(256), 0, st,
-                           h->P_actor(), h->ov, s0, s1, hp, tk);
+        const PackSet3 s3{h->d_xtiles, h->x3_live ? h->x3_tiles : 0, h->xpack};
+        hipLaunchKernelGGL(pack_actor_kernel, dim3(s0.n_tiles + s0.n_vecs + s1.n_tiles + s1.n_vecs + 1 + s3.n_tiles), dim3(256), 0, st,
+                           h->P_actor(), h->ov, s0, s1, hp, tk, s3);
     }
 }
 
@@ -1758,6 +1853,8 @@ int tvc_sac_snapshot_policy(tvc_sac* h, void* stream) {
     if (h->rows_ok) TVC_HIP_CHECK(hipMemcpyAsync(h->snap_pack, h->pack, h->pack_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (h->train_rows_ok && h->train_stream_live)
         TVC_HIP_CHECK(hipMemcpyAsync(h->snap_tpack, h->tpack, h->tpack_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (h->x3_live)
+        TVC_HIP_CHECK(hipMemcpyAsync(h->snap_xpack, h->xpack, (size_t)h->x3_tiles * X3_TILE_BYTES, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
