@@ -89,6 +89,11 @@ def parse():
                          "a whole-step graph cannot hold the RCCL calls)")
     ap.add_argument("--acting-dropout", action="store_true", help="train: act in train mode like the reference's get_action "
                                                                   "(Dropout(0.1) live in the policy, agent/...:765)")
+    ap.add_argument("--acting-x3", action="store_true",
+                    help="train: the one-launch acting kernel on the bf16 matrix pipe with three-term split operands (fp32-exact, "
+                         "tvc_actor_x3.h) instead of the f32-input MFMA; without the flag the default run reports it as the extra "
+                         "`acting_x3` leg")
+    ap.add_argument("--no-x3-leg", action="store_true", help="skip the extra split-operand leg of the default run")
     ap.add_argument("--prefill-steps", type=int, default=1000,
                     help="train: random-action env steps before the warm-up so that the timed steps see the long-run env state (reward "
                          "histories full: from step 1000 of a run the step kernel scans a whole 1000-entry ring per env)")
@@ -415,7 +420,8 @@ def main():
         "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if not getattr(args, "acting_x3", False) else "f32 (acting pass: fp32 operands split in three bf16 terms, six products on the "
+                                                                       "bf16 matrix pipe, fp32 accumulate; update: f32-input MFMA)",
         "data": "synthetic",
         "world_size": world,
         "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else "none (single rank)",
@@ -458,6 +464,18 @@ def main():
         except Exception as e:
             out["shard_sizes"] = {"error": f"{type(e).__name__}: {e}"}
 
+    if workload == "train" and world == 1 and not args.loop_only and not args.no_x3_leg and not args.acting_x3 \
+            and args.family == 0 and n >= 16384 and not args.acting_dropout and not args.shipped_acting:
+        # the same loop with the acting pass on the bf16 matrix pipe (split operands, fp32-exact): reported NEXT TO the headline, which
+        # keeps the f32-input MFMA kernel
+        try:
+            if tr is not None:
+                tr.close()
+                tr = None
+            out["acting_x3"] = x3_leg(args, device, n, K, W)
+        except Exception as e:
+            out["acting_x3"] = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         try:
             if not args.loop_only:
@@ -475,6 +493,47 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def x3_leg(args, device, n, K, W):
+    """The headline workload again with VecTrainer(acting_x3=True): every Linear of the acting pass on v_mfma_f32_16x16x32_bf16 with both
+    operands split in three bf16 terms and six products accumulated in fp32 (tvc_actor_x3.h).  Same K / W, same tuning steps."""
+    import copy
+    from tvc_ai_amd import trainer
+    a2 = copy.copy(args)
+    a2.acting_x3 = True
+    res = trainer.bench_train(a2, 1, 0, device, n_envs=n)
+    t = res["trainer"]
+    dt, _, _ = timed_steps(res["step_fn"], K, W, 1, device, False)
+    rep = {"value": n * K / dt, "unit": "env-steps/s", "ms_per_step": dt / K * 1e3, "sac_updates_per_s": t.updates_per_step * K / dt,
+           "steps": K, "warmup": W, "share_rows": t.share_rows,
+           "arithmetic": "v_mfma_f32_16x16x32_bf16, operands x = x_h + x_m + x_l (bf16 each, 24 mantissa bits in all), products hh hm mh hl lh mm, "
+                         "fp32 accumulate; error against an fp64 evaluation equal to the f32-input MFMA kernel's (tests/test_acting_x3_gpu.py)",
+           "kernel": x3_kernel_roofline(n, device)}
+    t.close()
+    return rep
+
+
+BF16_MFMA_PEAK_TF = 2500.0  # dense, guide
+
+
+def x3_kernel_roofline(n, device):
+    """isolated launch of actor_x3_kernel: algorithmic flops (3.29 MFLOP per row, as for the f32 kernel) / time against the roof of THIS
+    arithmetic, the bf16 dense peak / 6 (every algorithmic multiply-add is six bf16 ones); also the executed bf16 rate"""
+    from tvc_ai_amd.agent import NativeSAC, sac_cfg
+    sacr = NativeSAC(sac_cfg(0, batch_size=256, max_act_rows=n), device=device, seed=2)
+    ob, ep = torch.randn(n, 10, device=device), torch.randn(n, 2, device=device)
+    outs = tuple(torch.empty(n, 2, device=device) for _ in range(3))
+    us = graph_time_us(lambda k: sacr.act(ob, ep, out=outs, x3=True), 5, device)
+    sacr.close()
+    macs = 16 * 256 + 3 * 256 * 256 + 4 * (2 * 256 * 512) + 256 * 512 + 512 * 512 + 512 * 4
+    flops = 2.0 * macs * n
+    tf = flops / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "kernel": "tvcnn::actor_x3_kernel", "achieved": tf, "peak": BF16_MFMA_PEAK_TF / 6.0, "unit": "TFLOP/s",
+            "frac": tf / (BF16_MFMA_PEAK_TF / 6.0), "launch_us": us, "flops_per_launch": flops, "flops_per_row": 2.0 * macs,
+            "executed_bf16_tflops": 6.0 * tf, "bf16_dense_peak_tflops": BF16_MFMA_PEAK_TF,
+            "times_the_f32_mfma_peak": tf / MFMA_F32_PEAK_TF,
+            "note": "achieved = algorithmic flops / time; peak = bf16 dense peak / 6 products; launch time live (hipGraph of 5 isolated launches)"}
 
 
 def shard_sizes(args, device, sizes=(4096, 8192), K=200, W=30):
@@ -663,7 +722,10 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device,
         # the whole acting pass as one launch: from 16 384 rows the row-owner kernel (csrc/tvc_actor_rows.h: 64 rows per workgroup),
         # from 1 024 rows its split sibling (csrc/tvc_actor_split.h: 16 rows per workgroup, the four waves split every Linear)
         rows_kernel = args.family == 0 and n >= 1024
-        if rows_kernel:
+        if rows_kernel and getattr(args, "acting_x3", False) and n >= 16384:
+            rep["roofline"] = x3_kernel_roofline(n, device)
+            rep["roofline"].update({"traffic": None, "in_loop_us": None})
+        elif rows_kernel:
             # dominant kernel of the train loop = the WHOLE acting pass as one launch: every Linear of the policy on
             # v_mfma_f32_16x16x4_f32 (dense f32 peak 157.3 TFLOP/s), activations in registers, weights streamed through LDS.
             # flops per launch = 2 x MACs per row (as executed: embedding folded into layer 0, attention folded to one 256x256

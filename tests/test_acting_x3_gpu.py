@@ -93,3 +93,31 @@ def test_x3_stream_is_repacked_by_a_policy_update():
     m_ref, _ = _ref64(P, obs[pick])
     assert float((m3.cpu()[pick].double() - m_ref).abs().max()) <= 3e-4
     sac.close()
+
+
+def test_train_loop_with_x3_acting_matches_the_f32_loop_on_its_first_step_and_stays_finite():
+    """VecTrainer(acting_x3=True): snapshot + split (share-CUs / exclusive) forms of actor_x3_kernel in the two-stream loop.  The first
+    step's actions equal the f32 loop's to rounding (same seeds, same policy); after that the trajectories may part at threshold
+    terms, so the rest is a finiteness / progress check."""
+    from tvc_ai_amd.trainer import VecTrainer
+    n = 32768
+    acts, tr = [], None
+    for x3 in (False, True):
+        tr = VecTrainer(n, family=0, batch_size=64, replay_capacity=1 << 17, seed=3, acting_x3=x3, defer_join=True)
+        torch.manual_seed(7)  # (the acting noise comes from torch's global generator)
+        tr.step(True)
+        torch.cuda.synchronize()
+        acts.append(tr.act.clone())
+        if not x3:
+            tr.close()
+    d = float((acts[0] - acts[1]).abs().max())
+    assert d <= 5e-5, d
+    for _ in range(6):
+        tr.step(True)
+    torch.cuda.synchronize()
+    st = tr.stats()
+    assert all(np.isfinite(st["losses"])), st
+    assert torch.isfinite(tr.act).all()
+    from tests import parity_log
+    parity_log.record("train_loop_x3_first_step_action_diff", max_abs_diff=d, envs=n)
+    tr.close()

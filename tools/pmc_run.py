@@ -28,7 +28,7 @@ elif mode == "act":
         ob, ep = torch.randn(n, 10, device="cuda"), torch.randn(n, 2, device="cuda")
         outs = tuple(torch.empty(n, 2, device="cuda") for _ in range(3))
         for _ in range(10):
-            sac.act(ob, ep, out=outs)
+            sac.act(ob, ep, out=outs, x3=os.environ.get("TVC_ACT_X3", "0") == "1")
         torch.cuda.synchronize()
         sac.close()
 elif mode in ("envdr", "envdr1000"):  # envdr1000: the train loop's instantiation <W1000, DR> (reference-exact 1000-entry reward history)

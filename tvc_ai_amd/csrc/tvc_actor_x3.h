@@ -29,59 +29,112 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-constexpr int X3_TILE_F4 = X3_TILE_BYTES / 16;
 constexpr int X3_PARK = 6;   // activation tiles of the head parked in LDS (see actor_x3_kernel)
 
 #ifndef X3_NW
 #define X3_NW 4   // waves (16 rows each) per workgroup sharing one tile stream
 #endif
-struct X3Pipe {
-    const char* tiles; char* Bs;
-    int ti, n_tiles;
-    int wave;
-    unsigned goff;   // (wave * 384 + lane) * 16: this lane's byte offset inside a tile
-};
+#ifndef X3_KT
+#define X3_KT 8     // triples per ring slot (a slot = X3_KT x 3 KB); the packed stream's 24 KB tiles are X3_TRI / X3_KT consecutive slots
+#endif
+#ifndef X3_NBUF
+#define X3_NBUF 2   // ring slots: the copy of slot s + X3_NBUF - 1 is issued at the barrier that opens slot s
+#endif
 #ifndef X3_ABL
-#define X3_ABL 0   // timing-only ablations (wrong results): 1 = stream wraps after 32 tiles (L2-resident), 2 = no copies after the first two
-#endif             // tiles, 3 = no workgroup barrier (waits kept)
+#define X3_ABL 0   // timing-only ablations (wrong results): 1 = stream wraps after 768 KB (L2-resident), 2 = no copies after the first
+#endif             // slots, 3 = no workgroup barrier (waits kept)
 #ifndef X3_DEPTH
 #define X3_DEPTH 2  // fragment register sets: the reads of triple g + X3_DEPTH - 1 are issued before the MFMAs of triple g
 #endif
-__device__ __forceinline__ void x3_issue_tile(const X3Pipe& p, int ti) {
-    // 24 KB = 4 waves x 6 wave-instructions x 1 KB, lane-linear image; the immediate offset (< 4096) advances both addresses
-    // scalar tile base + one 32-bit lane offset (the saddr form); the product is made in SGPRs so that hipcc does not fold the
-    // loop-invariant (stream base + lane offset) into a per-lane 64-bit pointer that it then spills and reloads once per tile
+constexpr int X3_SLOT_BYTES = X3_KT * 3072;
+constexpr int X3_CPW = X3_SLOT_BYTES / 1024 / X3_NW;  // copy instructions (1 KB each) per wave and slot
+static_assert(X3_CPW * 1024 * X3_NW == X3_SLOT_BYTES && X3_CPW <= 8, "slot = waves x (<= 8 pieces of 1 KB: two address pairs + immediate offsets)");
+struct X3Pipe {
+    const char* tiles; char* Bs;
+    int ti, n_tiles;   // in slots
+    int cp_ti;         // slot whose copy the last x3_next started (>= n_tiles: none)
+    int wave;
+    unsigned goff;     // (wave * X3_CPW * 64 + lane) * 16: this lane's byte offset inside a slot
+#ifdef X3_WAITS
+    unsigned long long w_vm, w_lgkm, w_bar, w_issue;   // cycles of wave 0 in the copy wait / LDS wait / barrier / copy issue of x3_next
+#endif
+};
+#ifndef X3_SPREAD
+#define X3_SPREAD 0   // 1: the copy pieces of the next slot go out one per triple behind the barrier instead of all at once.  Measured
+#endif                // SLOWER (2 001 vs 1 205 us at 65 536 rows): an LDS-DMA between fragment reads costs more than the burst's queueing
+// piece c (1 KB per wave) of slot ti; the immediate offset (< 4096) advances both the global and the LDS address
+template <int C>
+__device__ __forceinline__ void x3_issue_piece(const X3Pipe& p, int ti) {
+    // scalar slot base + one 32-bit lane offset (the saddr form); the product is made in SGPRs so that hipcc does not fold the
+    // loop-invariant (stream base + lane offset) into a per-lane 64-bit pointer that it then spills and reloads once per slot
 #if X3_ABL == 1
-    const size_t toff = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((ti & 31) * X3_TILE_BYTES);
+    const size_t toff = (size_t)(unsigned)__builtin_amdgcn_readfirstlane((ti & 31) * X3_SLOT_BYTES + (C >> 2) * 4096);
 #else
-    const size_t toff = (size_t)(unsigned)__builtin_amdgcn_readfirstlane(ti * X3_TILE_BYTES);
+    const size_t toff = (size_t)(unsigned)__builtin_amdgcn_readfirstlane(ti * X3_SLOT_BYTES + (C >> 2) * 4096);
 #endif
     const char* src = p.tiles + toff + p.goff;
-    char* dst = p.Bs + (ti & 1) * X3_TILE_BYTES + p.wave * (X3_TILE_BYTES / X3_NW);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 1024, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 2048, 0);
-#if X3_NW == 4
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 3072, 0);
-    const char* src2 = src + 4096;
-    char* dst2 = dst + 4096;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src2, (__attribute__((address_space(3))) void*)dst2, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src2, (__attribute__((address_space(3))) void*)dst2, 16, 1024, 0);
+    char* dst = p.Bs + (ti & (X3_NBUF - 1)) * X3_SLOT_BYTES + p.wave * (X3_SLOT_BYTES / X3_NW) + (C >> 2) * 4096;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, (C & 3) * 1024, 0);
+}
+__device__ __forceinline__ void x3_issue_tile(const X3Pipe& p, int ti) {
+    x3_issue_piece<0>(p, ti);
+    if (X3_CPW > 1) x3_issue_piece<1>(p, ti);
+    if (X3_CPW > 2) x3_issue_piece<2>(p, ti);
+    if (X3_CPW > 3) x3_issue_piece<3>(p, ti);
+    if (X3_CPW > 4) x3_issue_piece<4>(p, ti);
+    if (X3_CPW > 5) x3_issue_piece<5>(p, ti);
+    if (X3_CPW > 6) x3_issue_piece<6>(p, ti);
+    if (X3_CPW > 7) x3_issue_piece<7>(p, ti);
+}
+// piece C of the slot whose copy the last x3_next started (X3_SPREAD: called behind the MFMAs of the C-th triple after that barrier)
+__device__ __forceinline__ void x3_spread_piece(const X3Pipe& p, int c) {   // c folds to a constant in the unrolled passes
+#if X3_SPREAD
+    if (c < 1 || c >= X3_CPW || p.cp_ti >= p.n_tiles) return;
+    if (c == 1) x3_issue_piece<1>(p, p.cp_ti);
+    else if (c == 2) x3_issue_piece<2>(p, p.cp_ti);
+    else if (c == 3) x3_issue_piece<3>(p, p.cp_ti);
+    else if (c == 4) x3_issue_piece<4>(p, p.cp_ti);
+    else if (c == 5) x3_issue_piece<5>(p, p.cp_ti);
+    else if (c == 6) x3_issue_piece<6>(p, p.cp_ti);
+    else x3_issue_piece<7>(p, p.cp_ti);
 #endif
 }
-// make tile p.ti readable, start the copy of tile p.ti + 1 into the buffer tile p.ti - 1 just vacated (see ar_next)
+// Make slot p.ti readable, start the copy of slot p.ti + X3_NBUF - 1 into the slot that p.ti - 1 just vacated, return the readable slot.
+// Before the barrier: my share of slot p.ti has landed and my fragment reads of slot p.ti - 1 are back.  FULL: issue every piece here
+// (a caller that does not run the triples of this slot); otherwise with X3_SPREAD only piece 0, the rest through x3_spread_piece.
+template <bool FULL = false>
 __device__ __forceinline__ const char* x3_next(X3Pipe& p) {
-#if X3_ABL == 3
+#ifdef X3_WAITS
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+#elif X3_ABL == 3
     __builtin_amdgcn_s_waitcnt(0x0070);
     __builtin_amdgcn_sched_barrier(0);
+#elif X3_NBUF == 2
+    __syncthreads();   // = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier, and hipcc's waitcnt pass knows the counters are zero behind it
 #else
-    __syncthreads();
+    constexpr int INFL = (X3_NBUF - 2) * X3_CPW;   // copy instructions of newer slots allowed to stay in flight
+    static_assert(INFL <= 15, "vmcnt field");
+    if (p.ti + X3_NBUF - 2 < p.n_tiles) __builtin_amdgcn_s_waitcnt(0x0070 | INFL);   // vmcnt(INFL) lgkmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x0070);
+    __builtin_amdgcn_s_barrier();
 #endif
-    const char* cur = p.Bs + (p.ti & 1) * X3_TILE_BYTES;
+    const char* cur = p.Bs + (p.ti & (X3_NBUF - 1)) * X3_SLOT_BYTES;
+    p.cp_ti = p.ti + X3_NBUF - 1;
 #if X3_ABL == 2
-    if (p.ti + 1 < 2) x3_issue_tile(p, p.ti + 1);
-#else
-    if (p.ti + 1 < p.n_tiles) x3_issue_tile(p, p.ti + 1);
+    if (p.cp_ti >= X3_NBUF) p.cp_ti = p.n_tiles;
+#endif
+    if (p.cp_ti < p.n_tiles) {
+        if (FULL || !X3_SPREAD) x3_issue_tile(p, p.cp_ti); else x3_issue_piece<0>(p, p.cp_ti);
+    }
+#ifdef X3_WAITS
+    const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+    p.w_vm += t1 - t0; p.w_lgkm += t2 - t1; p.w_bar += t3 - t2; p.w_issue += t4 - t3;
 #endif
     p.ti += 1;
     return cur;
@@ -162,7 +215,7 @@ __device__ __forceinline__ f32x4 x3_mfma6(const u32x4_t (&w)[3], const X3Op& x, 
 template <int NT, int KB, bool PIPE = true, int PARK0 = -1>
 __device__ __forceinline__ void x3_pass(X3Pipe& p, const f32x4* __restrict__ x, f32x4* __restrict__ acc, unsigned lane16,
                                         const f32x4* park = nullptr) {
-    static_assert((NT * KB) % X3_TRI == 0, "a pass is a whole number of tiles");
+    static_assert((NT * KB) % X3_KT == 0, "a pass is a whole number of ring slots");
     constexpr int VPT = (44 + NT - 1) / NT;  // VALU instructions of the NEXT block's split placed behind each triple of this block
     auto src = [&](int i) -> f32x4 { return (PARK0 >= 0 && i >= PARK0) ? park[(i - PARK0) * (64 * X3_NW)] : x[i]; };
     // fragment ring: X3_DEPTH register sets; the reads of triple g + X3_DEPTH - 1 go out before the MFMAs of triple g.  A read of the
@@ -172,6 +225,7 @@ __device__ __forceinline__ void x3_pass(X3Pipe& p, const f32x4* __restrict__ x, 
     const char* base = x3_next(p) + lane16;
 #pragma unroll
     for (int a = 0; a < D - 1 && a < NTRI; ++a) x3_frag(w[a], base, a);
+    static_assert(D - 1 <= X3_KT, "the read-ahead stays inside the first slot of a pass");
     X3Op xo = x3_split(src(0), src(1));
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
@@ -186,10 +240,11 @@ __device__ __forceinline__ void x3_pass(X3Pipe& p, const f32x4* __restrict__ x, 
         for (int t = 0; t < NT; ++t) {
             const int g = kb * NT + t, ga = g + D - 1;
             if (ga < NTRI) {
-                if (ga % X3_TRI == 0) base = x3_next(p) + lane16;
-                x3_frag(w[ga % D], base, ga % X3_TRI);
+                if (ga % X3_KT == 0) base = x3_next(p) + lane16;
+                x3_frag(w[ga % D], base, ga % X3_KT);
             }
             acc[t] = x3_mfma6(w[g % D], xo, acc[t]);
+            if (ga < NTRI) x3_spread_piece(p, ga % X3_KT);   // (ga % X3_KT == 0: piece 0 went out inside x3_next)
             if (PIPE && t == 0 && kb + 1 < KB) xn = x3_split(src(2 * kb + 2), src(2 * kb + 3));
             __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);    // the three reads of the triple ahead first ...
             __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    // ... then this triple's six MFMAs ...
@@ -205,7 +260,7 @@ __global__ void __launch_bounds__(256, 2) actor_x3_kernel(ActRowsArgs a) {
 #else
 __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
 #endif
-    __shared__ __attribute__((aligned(16))) char Bs[2 * X3_TILE_BYTES];  // two 24 KB weight tiles
+    __shared__ __attribute__((aligned(16))) char Bs[X3_NBUF * X3_SLOT_BYTES];  // the weight ring (2 x 24 KB)
     // ... and 24 KB where the head parks the last six tiles of its 512-wide activation (24 registers per lane) while it is the
     // B operand of policy_head.4: 128 (activation) + 64 (accumulators) + fragments + split do not fit 256 registers, and what hipcc
     // spills goes to scratch = the Infinity Cache and back
@@ -224,8 +279,9 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
     }
     int tr = 6; (void)tr;  // AR_TRACE: stamps 6.. = s_memtime of wave 0 after every pass / epilogue
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    X3Pipe p{reinterpret_cast<const char*>(a.tiles), Bs, 0, a.n_tiles, wv, (unsigned)((wv * (1536 / X3_NW) + lane) * 16)};
-    x3_issue_tile(p, 0);
+    X3Pipe p{reinterpret_cast<const char*>(a.tiles), Bs, 0, a.n_tiles * (X3_TRI / X3_KT), 0, wv, (unsigned)((wv * X3_CPW * 64 + lane) * 16)};
+#pragma unroll
+    for (int s0 = 0; s0 < X3_NBUF - 1; ++s0) x3_issue_tile(p, s0);
     const unsigned lane16 = lane * 16;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -284,7 +340,8 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
         const float* sv = tv + AR_TAIL_VEC;
         f32x4 s4[1] = {zero4};
         x3_pass<1, 8>(p, x, s4, lane16); AR_T();   // fc1 (256 -> 16): one tile
-        (void)x3_next(p);                  // + an all-zero tile: every pass an even number of tiles (ring parity)
+#pragma unroll
+        for (int z = 0; z < X3_TRI / X3_KT; ++z) (void)x3_next<true>(p);   // + the all-zero tile behind it in the stream
         const f32x4 b1 = *reinterpret_cast<const f32x4*>(sv + 4 * q);
         f32x4 yy[2];
 #pragma unroll
@@ -353,6 +410,11 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
     if (a.stamps && tid == 0) {
         a.stamps[AR_STAMPS * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
         a.stamps[AR_STAMPS * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+#ifdef X3_WAITS
+        static_assert(AR_STAMPS >= 96, "X3_WAITS needs -DAR_TRACE (96 stamp slots per workgroup)");
+        a.stamps[AR_STAMPS * blockIdx.x + 90] = p.w_vm; a.stamps[AR_STAMPS * blockIdx.x + 91] = p.w_lgkm;
+        a.stamps[AR_STAMPS * blockIdx.x + 92] = p.w_bar; a.stamps[AR_STAMPS * blockIdx.x + 93] = p.w_issue;
+#endif
     }
     if (q == 0 && row < a.M) {
         for (int j = 0; j < a.A; ++j) {

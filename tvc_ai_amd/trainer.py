@@ -28,7 +28,7 @@ class VecTrainer:
                  max_episode_steps: int = 1000, enable_curiosity: bool = False, overlap: bool = True,
                  enable_hierarchical: bool = False, enable_safety: bool = False, dropout_p: Optional[float] = None,
                  share_cus: Optional[bool] = None, defer_join: bool = False, share_rows: Optional[int] = None,
-                 acting_dropout: bool = False, **env_over):
+                 acting_dropout: bool = False, acting_x3: bool = False, **env_over):
         self.device = torch.device(device)
         self.n, self.B, self.world, self.rank = num_envs, batch_size, world, rank
         self.updates_per_step = updates_per_step
@@ -78,6 +78,11 @@ class VecTrainer:
         # acting_dropout = True: act in train mode like the reference's get_action (agent/...:765): Dropout live in the policy
         # (attention not folded; one launch from 1 024 rows: actor_split_kernel<true>); False = the deterministic folded net
         self.acting_dropout = bool(acting_dropout) and self.dropout_p > 0.0
+        # acting_x3 = True: the one-launch acting kernel (>= 16 384 rows) runs on the bf16 matrix pipe with three-term split operands,
+        # fp32-exact (tvc_actor_x3.h, tvc_sac_act flags bit 4); its weight stream is packed now, before any update can run beside it
+        self.acting_x3 = bool(acting_x3) and family == 0 and not self.acting_dropout
+        if self.acting_x3:
+            self.sac.enable_x3()
         # intrinsic curiosity bonus of the reference's training env (scripts/train.py:318, env/...:496-502)
         self.curiosity = None
         if enable_curiosity:
@@ -204,10 +209,11 @@ class VecTrainer:
             if 0 < k < self.n:  # two launches over row blocks: [0, k) leaves room for the update, [k, n) takes the whole chip
                 for lo, hi, sh in ((0, k, True), (k, self.n, False)):
                     self.sac.act(cur[lo:hi], self.eps_act[lo:hi], out=(raw[lo:hi], self.mean[lo:hi], self.ls[lo:hi]),
-                                 clamp=self.safety is None, snapshot=self._snapshot, share_cus=sh, train_mode=self.acting_dropout)
+                                 clamp=self.safety is None, snapshot=self._snapshot, share_cus=sh, train_mode=self.acting_dropout,
+                                 x3=self.acting_x3)
             else:
                 self.sac.act(cur, self.eps_act, out=(raw, self.mean, self.ls), clamp=self.safety is None, snapshot=self._snapshot,
-                             share_cus=share, train_mode=self.acting_dropout)
+                             share_cus=share, train_mode=self.acting_dropout, x3=self.acting_x3)
         if self.safety is not None:  # sees the unclamped sample; clamps its result
             self.safety.apply(cur, raw, out=self.act)
         o, rew, term, trunc, info = self.env.step(self.act, out_obs=nxt)
@@ -728,6 +734,7 @@ def bench_train(args, world, rank, device, n_envs=None):
                     defer_join=True,  # the bench synchronises the device around its timed region
                     share_rows=None if int(getattr(args, "share_rows", -1)) < 0 else int(args.share_rows),
                     acting_dropout=bool(getattr(args, "acting_dropout", False)),
+                    acting_x3=bool(getattr(args, "acting_x3", False)),
                     enable_hierarchical=shipped, enable_safety=shipped, enable_curiosity=shipped, **env_over)
     if stage is not None:  # the curriculum driver reads device-side episode statistics and owns the stage from here on
         from .curriculum import CurriculumDriver
@@ -760,6 +767,9 @@ def bench_train(args, world, rank, device, n_envs=None):
                                                       "acting_rows_in_sharing_form": tr.share_rows if tr.share_cus else 0,
                                                       "share_rows_tuning": tuning,
                                                       "acting_dropout": tr.acting_dropout,
+                                                      "acting_arithmetic": "bf16 matrix pipe, operands split in three bf16 terms, six products, fp32 accumulate "
+                                                                           "(fp32-exact: tests/test_acting_x3_gpu.py)" if tr.acting_x3
+                                                      else "f32-input MFMA (v_mfma_f32_16x16x4_f32)",
                                                       "acting": "hierarchical goal policy + safety layer + curiosity bonus (shipped config.yaml)"
                                                       if shipped else "SAC policy",
                                                       "reward_history_window": int(tr.env.cfg.distinct_window),
