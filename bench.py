@@ -529,8 +529,15 @@ def x3_kernel_roofline(n, device):
     macs = 16 * 256 + 3 * 256 * 256 + 4 * (2 * 256 * 512) + 256 * 512 + 512 * 512 + 512 * 4
     flops = 2.0 * macs * n
     tf = flops / (us * 1e-6) / 1e12
+    traffic = pmc_traffic(((n + 63) // 64) * 256, "tvcnn::actor_x3_kernel")
+    t_stale = STALE.get("traffic") if traffic else None
+    loop = in_loop_us("tvcnn::actor_x3_kernel", f"{n}_x3")
     return {"bound": "mfma", "kernel": "tvcnn::actor_x3_kernel", "achieved": tf, "peak": BF16_MFMA_PEAK_TF / 6.0, "unit": "TFLOP/s",
-            "frac": tf / (BF16_MFMA_PEAK_TF / 6.0), "launch_us": us, "flops_per_launch": flops, "flops_per_row": 2.0 * macs,
+            "frac": tf / (BF16_MFMA_PEAK_TF / 6.0), "traffic": traffic,
+            "traffic_source": f"{PMC_FILE} (committed rocprofv3 --pmc pass, not measured in this run)" if traffic else None,
+            "traffic_stale": t_stale, "in_loop_us": loop, "in_loop_stale": STALE.get("in_loop") if loop else None,
+            "in_loop_frac": (flops / (loop * 1e-6) / 1e12 / (BF16_MFMA_PEAK_TF / 6.0)) if loop else None,
+            "launch_us": us, "flops_per_launch": flops, "flops_per_row": 2.0 * macs,
             "executed_bf16_tflops": 6.0 * tf, "bf16_dense_peak_tflops": BF16_MFMA_PEAK_TF,
             "times_the_f32_mfma_peak": tf / MFMA_F32_PEAK_TF,
             "note": "achieved = algorithmic flops / time; peak = bf16 dense peak / 6 products; launch time live (hipGraph of 5 isolated launches)"}
@@ -724,7 +731,6 @@ def roofline_report(args, workload, n, physics_step_fn, dev_us_per_step, device,
         rows_kernel = args.family == 0 and n >= 1024
         if rows_kernel and getattr(args, "acting_x3", False) and n >= 16384:
             rep["roofline"] = x3_kernel_roofline(n, device)
-            rep["roofline"].update({"traffic": None, "in_loop_us": None})
         elif rows_kernel:
             # dominant kernel of the train loop = the WHOLE acting pass as one launch: every Linear of the policy on
             # v_mfma_f32_16x16x4_f32 (dense f32 peak 157.3 TFLOP/s), activations in registers, weights streamed through LDS.

@@ -21,13 +21,13 @@ for r in csv.DictReader(open(src)):
 # step kernel also runs in the prefill).  Profile with a FIXED split (--share-rows): the tuning at warm-up runs other splits.
 calls = {r["Name"]: (int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(src))}
 steps = next((c for k, (c, _) in calls.items() if "update_prep_kernel" in k), None)
-k = "tvcnn::actor_rows_kernel"
-full = next((n for n in calls if n.startswith(k)), None)
-if steps and full and calls[full][0] > steps:
-    rows[k + " [average of one launch]"] = rows[k]
-    rows[k] = calls[full][1] / 1e3 / steps
-    rows["_launches_per_step"] = {k: calls[full][0] / steps}
-    rows["_train_steps_profiled"] = steps
+for k in ("tvcnn::actor_rows_kernel", "tvcnn::actor_x3_kernel"):
+    full = next((n for n in calls if n.startswith(k)), None)
+    if steps and full and calls[full][0] > steps:
+        rows[k + " [average of one launch]"] = rows[k]
+        rows[k] = calls[full][1] / 1e3 / steps
+        rows.setdefault("_launches_per_step", {})[k] = calls[full][0] / steps
+        rows["_train_steps_profiled"] = steps
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tvc_ai_amd.build import sources_sha256  # noqa: E402
 rows["_lib_sources_sha256"] = sources_sha256()  # bench.py prints "stale": true beside in_loop_us when the library has moved on

@@ -32,7 +32,7 @@ write = collect(sys.argv[2], "WRITE_SIZE")
 out = defaultdict(dict)
 for (name, grid), f in fetch.items():
     if (name, grid) not in write or not ("env_step" in name or "gemm_kernel" in name or "gemm_rowln" in name or "actor_rows" in name
-                                         or "actor_split" in name):
+                                         or "actor_split" in name or "actor_x3" in name):
         continue
     w = write[(name, grid)]
     out[name][str(grid)] = {"lib_sources_sha256": SHA, "fetch_size_kib_raw": f, "write_size_kib": w, "hbm_read_bytes": f * 1024 * 2,

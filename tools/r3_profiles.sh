@@ -12,6 +12,11 @@ for n in 65536 8192 4096; do
   f=$(find /tmp/ks_$n -name "*kernel_stats.csv" | head -1); cp $f $O/train_loop_kernel_stats_$n.csv
   python3 tools/loop_stats_to_json.py $f $n $O/train_loop_kernel_stats.json > /dev/null
 done
+# the same loop with the split-operand acting kernel (bench.py --acting-x3)
+rm -rf /tmp/ks_x3
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_x3 -- python3 bench.py --loop-only --envs-per-gpu 65536 --steps 100 --warmup 20 --acting-x3 --share-rows 16384 > $O/loop_65536_x3.log 2>&1; echo "kernel stats x3 rc=$?"
+f=$(find /tmp/ks_x3 -name "*kernel_stats.csv" | head -1); cp $f $O/train_loop_kernel_stats_65536_x3.csv
+python3 tools/loop_stats_to_json.py $f 65536_x3 $O/train_loop_kernel_stats.json > /dev/null
 rm -rf /tmp/upd; timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d /tmp/upd -- python3 tools/learner_only.py 30 0 0.1 > $O/upd.log 2>&1
 (cd tools && python3 update_timeline.py $(find /tmp/upd -name "*kernel_trace.csv" | head -1) ../$O/update_timeline.md > /dev/null 2>&1); echo "update timeline rc=$?"
 python tools/update_bench.py > $O/update_bench.json 2>/dev/null
@@ -21,6 +26,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c/b -- python3 tools/pmc_run.py envdr 65536 4194304 >> $O/pmc_$c.log 2>&1
   timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c/c -- python3 tools/pmc_run.py act 4096 8192 32768 65536 >> $O/pmc_$c.log 2>&1
   timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c/d -- python3 tools/pmc_run.py env 65536 4194304 >> $O/pmc_$c.log 2>&1
+  TVC_ACT_X3=1 timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c/e -- python3 tools/pmc_run.py act 65536 >> $O/pmc_$c.log 2>&1
   echo "pmc $c done"
 done
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
@@ -41,6 +47,11 @@ run --workload train --envs-per-gpu 16384 --steps 300 --warmup 30
 run --workload train --envs-per-gpu 32768 --steps 300 --warmup 30
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --segments on
+run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --acting-x3
+run --workload train --envs-per-gpu 32768 --steps 300 --warmup 30 --acting-x3
+run --workload train --envs-per-gpu 16384 --steps 300 --warmup 30 --acting-x3
+run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --acting-x3 --updates-per-step 2
+run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --acting-x3 --updates-per-step 4
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --acting-dropout
 run --workload train --envs-per-gpu 4096 --steps 300 --warmup 30 --acting-dropout --segments on
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --updates-per-step 2
@@ -57,5 +68,7 @@ python tools/env_ring_bench.py 4096 65536 1048576 2>/dev/null | grep envs > $O/e
 { echo "## tools/chain_bench.py: us per launch in a hipGraph chain of 64 dependent launches"; python tools/chain_bench.py 2>/dev/null | tail -1
   for mnk in "512 256 256" "512 256 512" "512 512 512"; do echo; echo "## tools/gemm_stamps.py $mnk (library built with -DTVC_GEMM_STAMPS)"; python tools/gemm_stamps.py $mnk 2>/dev/null | grep -v "^ *$"; done; } > $O/gemm_stamps.md
 echo "--- act bench" > $O/act_bench.txt; python tools/act_bench.py 1024 4096 8192 12288 16384 32768 65536 2>/dev/null | grep -v "^ *$" >> $O/act_bench.txt
+echo "--- act bench, split-operand kernel (tvc_sac_act flags bit 4)" >> $O/act_bench.txt; TVC_ACT_X3=1 python tools/act_bench.py 16384 32768 65536 262144 2>/dev/null | grep "^rows" >> $O/act_bench.txt
+bash tools/pmc_x3.sh > /dev/null 2>&1; cp gpurun_out/pmc_x3_summary.txt $O/pmc_x3_sq.txt
 cp gpurun_out/parity_summary.json $O/parity_summary.json 2>/dev/null
 ls $O

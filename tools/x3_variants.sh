@@ -2,6 +2,7 @@
 # acting bench of the split-operand kernel over library variants (TVC_HIP_LIB): x3_variants.sh <out> <name> ...   ("base" = the default library)
 out=$1; shift
 mkdir -p $(dirname $out); : > $out
+echo "== calibration: the f32-MFMA kernel on this box" >> $out; timeout -k 10 120 python tools/act_bench.py 65536 2>&1 | grep "^rows" >> $out
 for v in "$@"; do
   lib=tvc_ai_amd/csrc/libtvc_hip_$v.so; [ $v = base ] && lib=tvc_ai_amd/csrc/libtvc_hip.so
   echo "== $v" >> $out

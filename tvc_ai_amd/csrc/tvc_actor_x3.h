@@ -29,8 +29,14 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
-constexpr int X3_PARK = 6;   // activation tiles of the head parked in LDS (see actor_x3_kernel)
+#ifndef X3_PARK
+#define X3_PARK 8   // activation tiles of the head parked in LDS (see actor_x3_kernel)
+#endif
 
+#ifndef X3_STAGE
+#define X3_STAGE 0   // 1: the next slot travels through registers (two batches of three global_load_dwordx4 + ds_write_b128 per wave, the
+#endif               // loads behind the barrier / the fourth triple, the stores three triples later) instead of six LDS-DMA instructions.
+                     // Measured SLOWER (1 316 vs 1 191 us at 65 536 rows; 12 more live registers, 669 instead of 440 spills)
 #ifndef X3_NW
 #define X3_NW 4   // waves (16 rows each) per workgroup sharing one tile stream
 #endif
@@ -53,8 +59,12 @@ struct X3Pipe {
     const char* tiles; char* Bs;
     int ti, n_tiles;   // in slots
     int cp_ti;         // slot whose copy the last x3_next started (>= n_tiles: none)
+
     int wave;
     unsigned goff;     // (wave * X3_CPW * 64 + lane) * 16: this lane's byte offset inside a slot
+#if X3_STAGE
+    u32x4_t stg[3];    // register staging of the copy (X3_STAGE): three 1 KB pieces at a time, global_load_dwordx4 -> ds_write_b128
+#endif
 #ifdef X3_WAITS
     unsigned long long w_vm, w_lgkm, w_bar, w_issue;   // cycles of wave 0 in the copy wait / LDS wait / barrier / copy issue of x3_next
 #endif
@@ -99,6 +109,29 @@ __device__ __forceinline__ void x3_spread_piece(const X3Pipe& p, int c) {   // c
     else x3_issue_piece<7>(p, p.cp_ti);
 #endif
 }
+#if X3_STAGE
+static_assert(X3_CPW == 6 && X3_NBUF == 2 && X3_KT == 8, "register staging is written for 2 x 24 KB slots and four waves");
+template <int B>   // batch B (0 / 1) of slot p.cp_ti: pieces 3 B .. 3 B + 2 into the staging registers
+__device__ __forceinline__ void x3_stage_load(X3Pipe& p) {
+    if (p.cp_ti >= p.n_tiles) return;
+    const size_t toff = (size_t)(unsigned)__builtin_amdgcn_readfirstlane(p.cp_ti * X3_SLOT_BYTES + B * 3072);
+    const char* src = p.tiles + toff + p.goff;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p.stg[c] = *reinterpret_cast<const u32x4_t*>(src + c * 1024);
+}
+template <int B>
+__device__ __forceinline__ void x3_stage_store(X3Pipe& p) {
+    if (p.cp_ti >= p.n_tiles) return;
+    char* dst = p.Bs + (p.cp_ti & 1) * X3_SLOT_BYTES + p.wave * (X3_SLOT_BYTES / X3_NW) + B * 3072 + (p.goff & 1023u);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4_t*>(dst + c * 1024) = p.stg[c];
+}
+// called behind the MFMAs of every triple with c = read-ahead index inside the slot: batch 0 was loaded in x3_next
+__device__ __forceinline__ void x3_stage_step(X3Pipe& p, int c) {
+    if (c == 3) { x3_stage_store<0>(p); x3_stage_load<1>(p); }
+    else if (c == 7) x3_stage_store<1>(p);
+}
+#endif
 // Make slot p.ti readable, start the copy of slot p.ti + X3_NBUF - 1 into the slot that p.ti - 1 just vacated, return the readable slot.
 // Before the barrier: my share of slot p.ti has landed and my fragment reads of slot p.ti - 1 are back.  FULL: issue every piece here
 // (a caller that does not run the triples of this slot); otherwise with X3_SPREAD only piece 0, the rest through x3_spread_piece.
@@ -129,9 +162,14 @@ __device__ __forceinline__ const char* x3_next(X3Pipe& p) {
 #if X3_ABL == 2
     if (p.cp_ti >= X3_NBUF) p.cp_ti = p.n_tiles;
 #endif
+#if X3_STAGE
+    x3_stage_load<0>(p);
+    if (FULL) { x3_stage_store<0>(p); x3_stage_load<1>(p); x3_stage_store<1>(p); }
+#else
     if (p.cp_ti < p.n_tiles) {
         if (FULL || !X3_SPREAD) x3_issue_tile(p, p.cp_ti); else x3_issue_piece<0>(p, p.cp_ti);
     }
+#endif
 #ifdef X3_WAITS
     const unsigned long long t4 = __builtin_amdgcn_s_memtime();
     p.w_vm += t1 - t0; p.w_lgkm += t2 - t1; p.w_bar += t3 - t2; p.w_issue += t4 - t3;
@@ -166,6 +204,71 @@ __device__ __forceinline__ float x3_gelu(float x) {
     return fmaf(hx, e, hx);
 #else
     return gelu_f(x);
+#endif
+}
+// ... and four values at a time with packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of work per issue slot;
+// the library is built with -fno-slp-vectorize, so only explicit vector arithmetic is packed): 10 instead of 19 instructions per value
+#ifndef X3_PACKED
+#define X3_PACKED 3    // bit 0: GELU of the FFN, bit 1: LayerNorms, bit 2: GELU of policy_head.0, bit 3: the folded output head
+#endif
+__device__ __forceinline__ f32x4 x3_splat(float c) { return (f32x4){c, c, c, c}; }
+template <bool PK>
+__device__ __forceinline__ f32x4 x3_gelu4(const f32x4 x) {
+    if (PK) {
+    f32x4 z = x * 0.7071067811865476f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) z[r] = fminf(fmaxf(z[r], -4.0f), 4.0f);
+    const f32x4 x2 = z * z;
+    f32x4 p = x3_splat(-2.72614225801306e-10f);
+    p = __builtin_elementwise_fma(p, x2, x3_splat(2.77068142495902e-08f));
+    p = __builtin_elementwise_fma(p, x2, x3_splat(-2.10102402082508e-06f));
+    p = __builtin_elementwise_fma(p, x2, x3_splat(-5.69250639462346e-05f));
+    p = __builtin_elementwise_fma(p, x2, x3_splat(-7.34990630326855e-04f));
+    p = __builtin_elementwise_fma(p, x2, x3_splat(-2.95459980854025e-03f));
+    p = __builtin_elementwise_fma(p, x2, x3_splat(-1.60960333262415e-02f));
+    f32x4 q = x3_splat(-1.45660718464996e-05f);
+    q = __builtin_elementwise_fma(q, x2, x3_splat(-2.13374055278905e-04f));
+    q = __builtin_elementwise_fma(q, x2, x3_splat(-1.68282697438203e-03f));
+    q = __builtin_elementwise_fma(q, x2, x3_splat(-7.37332916720468e-03f));
+    q = __builtin_elementwise_fma(q, x2, x3_splat(-1.42647390514189e-02f));
+    f32x4 rq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rq[r] = __builtin_amdgcn_rcpf(q[r]);
+    const f32x4 e = z * p * rq;
+    const f32x4 hx = x * 0.5f;
+    return __builtin_elementwise_fma(hx, e, hx);
+    }
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = x3_gelu(x[r]);
+    return o;
+}
+// nn.LayerNorm over the 16 * NT features of each row like ar_layernorm (two-pass), packed arithmetic
+template <int NT>
+__device__ __forceinline__ void x3_layernorm(f32x4* __restrict__ u, const float* __restrict__ gamma, const float* __restrict__ beta, int q) {
+#if X3_PACKED & 2
+    f32x4 s4 = u[0];
+#pragma unroll
+    for (int t = 1; t < NT; ++t) s4 += u[t];
+    float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+    s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+    const float mean = s * (1.0f / (16.0f * NT));
+    const f32x4 m4 = x3_splat(mean);
+    f32x4 v4 = x3_splat(0.0f);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { const f32x4 d = u[t] - m4; v4 = __builtin_elementwise_fma(d, d, v4); }
+    float v = (v4[0] + v4[1]) + (v4[2] + v4[3]);
+    v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    const float rstd = rsqrtf(v * (1.0f / (16.0f * NT)) + 1e-5f);
+    const f32x4 r4 = x3_splat(rstd);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 g4 = ar_vec4(gamma, t, q), b4 = ar_vec4(beta, t, q);
+        u[t] = __builtin_elementwise_fma((u[t] - m4) * r4, g4, b4);
+        if (NT > 16 && (t & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // (see ar_layernorm)
+    }
+#else
+    ar_layernorm<NT>(u, gamma, beta, q);
 #endif
 }
 // two fp32 -> the bf16 pair of their three terms (low half = first value)
@@ -244,7 +347,11 @@ __device__ __forceinline__ void x3_pass(X3Pipe& p, const f32x4* __restrict__ x, 
                 x3_frag(w[ga % D], base, ga % X3_KT);
             }
             acc[t] = x3_mfma6(w[g % D], xo, acc[t]);
+#if X3_STAGE
+            if (ga < NTRI) x3_stage_step(p, ga % X3_KT);
+#else
             if (ga < NTRI) x3_spread_piece(p, ga % X3_KT);   // (ga % X3_KT == 0: piece 0 went out inside x3_next)
+#endif
             if (PIPE && t == 0 && kb + 1 < KB) xn = x3_split(src(2 * kb + 2), src(2 * kb + 3));
             __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);    // the three reads of the triple ahead first ...
             __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    // ... then this triple's six MFMAs ...
@@ -261,9 +368,9 @@ __global__ void __launch_bounds__(256, 2) actor_x3_kernel(ActRowsArgs a) {
 __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
 #endif
     __shared__ __attribute__((aligned(16))) char Bs[X3_NBUF * X3_SLOT_BYTES];  // the weight ring (2 x 24 KB)
-    // ... and 24 KB where the head parks the last six tiles of its 512-wide activation (24 registers per lane) while it is the
+    // ... and 32 KB where the head parks the last eight tiles of its 512-wide activation (32 registers per lane) while it is the
     // B operand of policy_head.4: 128 (activation) + 64 (accumulators) + fragments + split do not fit 256 registers, and what hipcc
-    // spills goes to scratch = the Infinity Cache and back
+    // spills goes to scratch = the Infinity Cache and back (two workgroups = exactly the CU's 160 KB; 6 tiles: 1 227 us, 8: 1 172)
     __shared__ __attribute__((aligned(16))) f32x4 Park[X3_PARK * 64 * X3_NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const int row = blockIdx.x * (16 * X3_NW) + wave * 16 + l15;
@@ -280,8 +387,13 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
     int tr = 6; (void)tr;  // AR_TRACE: stamps 6.. = s_memtime of wave 0 after every pass / epilogue
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     X3Pipe p{reinterpret_cast<const char*>(a.tiles), Bs, 0, a.n_tiles * (X3_TRI / X3_KT), 0, wv, (unsigned)((wv * X3_CPW * 64 + lane) * 16)};
+#if X3_STAGE
+    p.cp_ti = 0;
+    x3_stage_load<0>(p); x3_stage_store<0>(p); x3_stage_load<1>(p); x3_stage_store<1>(p);
+#else
 #pragma unroll
     for (int s0 = 0; s0 < X3_NBUF - 1; ++s0) x3_issue_tile(p, s0);
+#endif
     const unsigned lane16 = lane * 16;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -301,7 +413,7 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
         x3_pass<16, 1>(p, xin2, x, lane16); AR_T();
 #pragma unroll
         for (int t = 0; t < 16; ++t) x[t] += ar_vec4(vec, t, q);
-        ar_layernorm<16>(x, vec + 256, vec + 512, q); AR_T();
+        x3_layernorm<16>(x, vec + 256, vec + 512, q); AR_T();
     }
     for (int l = 0; l < a.n_layers; ++l) {
         const float* lv = vec + l * AR_LAYER_VEC;
@@ -311,7 +423,7 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
             x3_pass<16, 8>(p, x, acc, lane16); AR_T();
 #pragma unroll
             for (int t = 0; t < 16; ++t) x[t] += acc[t] + ar_vec4(lv, t, q);
-            ar_layernorm<16>(x, lv + 256, lv + 512, q); AR_T();
+            x3_layernorm<16>(x, lv + 256, lv + 512, q); AR_T();
         }
         // x = norm2(x + W2 gelu(W1 x + b1) + b2), the 512 hidden units in four quarters of 128 (32 registers of hidden activation)
         f32x4 acc2[16];
@@ -324,18 +436,22 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const f32x4 b4 = ar_vec4(lv + 768 + 128 * quarter, t, q);
+#if X3_PACKED & 1
+                h[t] = x3_gelu4<true>(h[t] + b4);
+#else
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[t][r] = x3_gelu(h[t][r] + b4[r]);
+#endif
             }
             AR_T();
             x3_pass<16, 4>(p, h, acc2, lane16); AR_T();
         }
 #pragma unroll
         for (int t = 0; t < 16; ++t) x[t] += acc2[t] + ar_vec4(lv + 1280, t, q);
-        ar_layernorm<16>(x, lv + 1536, lv + 1792, q); AR_T();
+        x3_layernorm<16>(x, lv + 1536, lv + 1792, q); AR_T();
     }
     const float* tv = vec + a.n_layers * AR_LAYER_VEC;
-    ar_layernorm<16>(x, tv, tv + 256, q); AR_T();  // feature_norm
+    x3_layernorm<16>(x, tv, tv + 256, q); AR_T();  // feature_norm
     if (a.use_se) {  // x *= sigmoid(fc2(relu(fc1(x))))
         const float* sv = tv + AR_TAIL_VEC;
         f32x4 s4[1] = {zero4};
@@ -365,15 +481,40 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
 #pragma unroll
     for (int t = 0; t < 32; ++t) {
         const f32x4 b4 = ar_vec4(tv + 512, t, q);
+#if X3_PACKED & 4
+        pp[t] = x3_gelu4<true>(pp[t] + b4);
+#else
 #pragma unroll
         for (int r = 0; r < 4; ++r) pp[t][r] = x3_gelu(pp[t][r] + b4[r]);
+#endif
         if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
-    ar_layernorm<32>(pp, tv + 1024, tv + 1536, q); AR_T();
+    x3_layernorm<32>(pp, tv + 1024, tv + 1536, q); AR_T();
     f32x4* park = Park + tid;
 #pragma unroll
     for (int i = 0; i < X3_PARK; ++i) park[i * (64 * X3_NW)] = pp[32 - X3_PARK + i];
     // ---- 512 -> 512 GELU LayerNorm -> 2A outputs, the LayerNorm + output Linear folded into running sums (see actor_rows_kernel)
+#if X3_PACKED & 8
+    f32x4 s1v = x3_splat(0.0f), s2v = x3_splat(0.0f), dv[4] = {x3_splat(0.0f), x3_splat(0.0f), x3_splat(0.0f), x3_splat(0.0f)};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f32x4 a2[16];
+        ar_zero<16>(a2);
+        x3_pass<16, 16, false, 32 - X3_PARK>(p, pp, a2, lane16, park); AR_T();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int tt = 16 * half + t;
+            const f32x4 v = x3_gelu4<true>(a2[t] + ar_vec4(tv + 2048, tt, q));
+            s1v += v;
+            s2v = __builtin_elementwise_fma(v, v, s2v);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) dv[o] = __builtin_elementwise_fma(v, ar_vec4(tv + 3584 + 512 * o, tt, q), dv[o]);
+        }
+    }
+    float s1 = (s1v[0] + s1v[1]) + (s1v[2] + s1v[3]), s2 = (s2v[0] + s2v[1]) + (s2v[2] + s2v[3]), d[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) d[o] = (dv[o][0] + dv[o][1]) + (dv[o][2] + dv[o][3]);
+#else
     float s1 = 0.0f, s2 = 0.0f, d[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -397,6 +538,7 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
             }
         }
     }
+#endif
 #define X3_RED(v) v += __shfl_xor(v, 16); v += __shfl_xor(v, 32)
     X3_RED(s1); X3_RED(s2);
 #pragma unroll
