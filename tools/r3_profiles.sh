@@ -3,7 +3,9 @@
 # sequence, PMC traffic passes (FETCH_SIZE / WRITE_SIZE in separate runs), the bench matrix and the default bench line.
 # Everything lands in gpurun_out/r03/; the summaries are then copied into profiles/ by hand.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03; rm -rf $O; mkdir -p $O
+O=gpurun_out/r03; mkdir -p $O
+PART=${1:-AB}
+if [[ $PART == *A* ]]; then
 python bench.py > $O/default_bench.json 2> $O/default_bench.err; echo "default bench rc=$?"
 for n in 65536 8192 4096; do
   extra="--share-rows 32768"; [ $n -lt 65536 ] && extra="--segments on"   # (a fixed split: the warm-up tuning would run other splits under the profiler)
@@ -31,6 +33,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
 python3 tools/pmc_to_json.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $O/pmc_traffic.json > /dev/null; echo "pmc json rc=$?"
+fi
+if [[ $PART == *B* ]]; then
 {
 echo "| workload | env-steps/s | ms/step | SAC updates/s | flags |"; echo "|---|---|---|---|---|"
 run() { python bench.py --loop-only "$@" 2>/dev/null | python -c "
@@ -72,3 +76,4 @@ echo "--- act bench, split-operand kernel (tvc_sac_act flags bit 4)" >> $O/act_b
 bash tools/pmc_x3.sh > /dev/null 2>&1; cp gpurun_out/pmc_x3_summary.txt $O/pmc_x3_sq.txt
 cp gpurun_out/parity_summary.json $O/parity_summary.json 2>/dev/null
 ls $O
+fi

@@ -37,6 +37,12 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #define X3_STAGE 0   // 1: the next slot travels through registers (two batches of three global_load_dwordx4 + ds_write_b128 per wave, the
 #endif               // loads behind the barrier / the fourth triple, the stores three triples later) instead of six LDS-DMA instructions.
                      // Measured SLOWER (1 316 vs 1 191 us at 65 536 rows; 12 more live registers, 669 instead of 440 spills)
+#ifndef X3_HQ
+#define X3_HQ 4   // output slices of policy_head.4 (2 = halves, 4 = quarters); the stream is packed to match (rows_tables_x3)
+#endif
+#ifndef X3_NOCSE
+#define X3_NOCSE 1
+#endif
 #ifndef X3_NW
 #define X3_NW 4   // waves (16 rows each) per workgroup sharing one tile stream
 #endif
@@ -432,6 +438,12 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
         for (int quarter = 0; quarter < 4; ++quarter) {
             f32x4 h[8];
             ar_zero<8>(h);
+#if X3_NOCSE
+            // hipcc otherwise keeps the split of x (8 k-blocks x 12 registers) alive across the four quarters to save 3 x 352 VALU
+            // instructions, and spills around it: the VALU count does not bound this kernel, the scratch traffic does
+#pragma unroll
+            for (int t = 0; t < 16; ++t) asm volatile("" : "+v"(x[t]));
+#endif
             x3_pass<8, 8>(p, x, h, lane16); AR_T();
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -494,36 +506,18 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
 #pragma unroll
     for (int i = 0; i < X3_PARK; ++i) park[i * (64 * X3_NW)] = pp[32 - X3_PARK + i];
     // ---- 512 -> 512 GELU LayerNorm -> 2A outputs, the LayerNorm + output Linear folded into running sums (see actor_rows_kernel)
-#if X3_PACKED & 8
-    f32x4 s1v = x3_splat(0.0f), s2v = x3_splat(0.0f), dv[4] = {x3_splat(0.0f), x3_splat(0.0f), x3_splat(0.0f), x3_splat(0.0f)};
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        f32x4 a2[16];
-        ar_zero<16>(a2);
-        x3_pass<16, 16, false, 32 - X3_PARK>(p, pp, a2, lane16, park); AR_T();
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int tt = 16 * half + t;
-            const f32x4 v = x3_gelu4<true>(a2[t] + ar_vec4(tv + 2048, tt, q));
-            s1v += v;
-            s2v = __builtin_elementwise_fma(v, v, s2v);
-#pragma unroll
-            for (int o = 0; o < 4; ++o) dv[o] = __builtin_elementwise_fma(v, ar_vec4(tv + 3584 + 512 * o, tt, q), dv[o]);
-        }
-    }
-    float s1 = (s1v[0] + s1v[1]) + (s1v[2] + s1v[3]), s2 = (s2v[0] + s2v[1]) + (s2v[2] + s2v[3]), d[4];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) d[o] = (dv[o][0] + dv[o][1]) + (dv[o][2] + dv[o][3]);
-#else
     float s1 = 0.0f, s2 = 0.0f, d[4] = {0.f, 0.f, 0.f, 0.f};
+    // policy_head.4 in X3_HQ output slices of 16 * HN features (4 quarters: 32 accumulators instead of 64 beside the 96 + 32 parked
+    // registers of the activation -- with halves hipcc kept 24 activation tiles in scratch and reloaded each behind a fresh tile copy)
+    constexpr int HN = 32 / X3_HQ;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        f32x4 a2[16];
-        ar_zero<16>(a2);
-        x3_pass<16, 16, false, 32 - X3_PARK>(p, pp, a2, lane16, park); AR_T();
+    for (int part = 0; part < X3_HQ; ++part) {
+        f32x4 a2[HN];
+        ar_zero<HN>(a2);
+        x3_pass<HN, 16, false, 32 - X3_PARK>(p, pp, a2, lane16, park); AR_T();
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int tt = 16 * half + t;
+        for (int t = 0; t < HN; ++t) {
+            const int tt = HN * part + t;
             const f32x4 b4 = ar_vec4(tv + 2048, tt, q);
             f32x4 gw[4];
 #pragma unroll
@@ -536,9 +530,13 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
 #pragma unroll
                 for (int o = 0; o < 4; ++o) d[o] = fmaf(v, gw[o][r], d[o]);
             }
+            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (keeps the vector loads of four tiles, not sixteen, in flight)
         }
+        // a slice's epilogue must not sink into the next slice's pass (hipcc moves it towards the use of its sums, behind that
+        // pass: its accumulators live beside the next ones, the hoisted vector loads spilled, every reload a vmcnt(0) behind a fresh copy)
+        asm volatile("" : "+v"(s1), "+v"(s2), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+        __builtin_amdgcn_sched_barrier(0);
     }
-#endif
 #define X3_RED(v) v += __shfl_xor(v, 16); v += __shfl_xor(v, 32)
     X3_RED(s1); X3_RED(s2);
 #pragma unroll

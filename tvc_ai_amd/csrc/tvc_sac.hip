@@ -1085,7 +1085,8 @@ static void rows_tables_x3(const tvc_sac_cfg& c, const NetDef& actor, const Fold
         pass(off("se_block.fc2.weight"), 16, 0, 0, 16, 1, 16, d, 0); // [256][16]: two tiles
     }
     for (int half = 0; half < 2; ++half) pass(off("policy_head.0.weight"), d, 256 * half, 0, 16, 8, d, d, 0);
-    for (int half = 0; half < 2; ++half) pass(off("policy_head.4.weight"), 512, 256 * half, 0, 16, 16, 512, d, 0);
+    for (int part = 0; part < X3_HQ; ++part)
+        pass(off("policy_head.4.weight"), 512, (512 / X3_HQ) * part, 0, 32 / X3_HQ, 16, 512, 512 / X3_HQ, 0);
 }
 
 // Train-mode stream: embedding (one tile), then per encoder layer v_proj (16 tiles), out_proj (16), the FFN as in rows_tables(),
