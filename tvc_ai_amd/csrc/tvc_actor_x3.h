@@ -33,15 +33,11 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #define X3_PARK 8   // activation tiles of the head parked in LDS (see actor_x3_kernel)
 #endif
 
-#ifndef X3_STAGE
-#define X3_STAGE 0   // 1: the next slot travels through registers (two batches of three global_load_dwordx4 + ds_write_b128 per wave, the
-#endif               // loads behind the barrier / the fourth triple, the stores three triples later) instead of six LDS-DMA instructions.
-                     // Measured SLOWER (1 316 vs 1 191 us at 65 536 rows; 12 more live registers, 669 instead of 440 spills)
 #ifndef X3_HQ
 #define X3_HQ 4   // output slices of policy_head.4 (2 = halves, 4 = quarters); the stream is packed to match (rows_tables_x3)
 #endif
 #ifndef X3_NOCSE
-#define X3_NOCSE 1
+#define X3_NOCSE 1   // the split of x is recomputed per FFN quarter instead of kept in 96 registers across them (see the layer loop)
 #endif
 #ifndef X3_NW
 #define X3_NW 4   // waves (16 rows each) per workgroup sharing one tile stream
@@ -65,19 +61,12 @@ struct X3Pipe {
     const char* tiles; char* Bs;
     int ti, n_tiles;   // in slots
     int cp_ti;         // slot whose copy the last x3_next started (>= n_tiles: none)
-
     int wave;
     unsigned goff;     // (wave * X3_CPW * 64 + lane) * 16: this lane's byte offset inside a slot
-#if X3_STAGE
-    u32x4_t stg[3];    // register staging of the copy (X3_STAGE): three 1 KB pieces at a time, global_load_dwordx4 -> ds_write_b128
-#endif
 #ifdef X3_WAITS
     unsigned long long w_vm, w_lgkm, w_bar, w_issue;   // cycles of wave 0 in the copy wait / LDS wait / barrier / copy issue of x3_next
 #endif
 };
-#ifndef X3_SPREAD
-#define X3_SPREAD 0   // 1: the copy pieces of the next slot go out one per triple behind the barrier instead of all at once.  Measured
-#endif                // SLOWER (2 001 vs 1 205 us at 65 536 rows): an LDS-DMA between fragment reads costs more than the burst's queueing
 // piece c (1 KB per wave) of slot ti; the immediate offset (< 4096) advances both the global and the LDS address
 template <int C>
 __device__ __forceinline__ void x3_issue_piece(const X3Pipe& p, int ti) {
@@ -102,46 +91,11 @@ __device__ __forceinline__ void x3_issue_tile(const X3Pipe& p, int ti) {
     if (X3_CPW > 6) x3_issue_piece<6>(p, ti);
     if (X3_CPW > 7) x3_issue_piece<7>(p, ti);
 }
-// piece C of the slot whose copy the last x3_next started (X3_SPREAD: called behind the MFMAs of the C-th triple after that barrier)
-__device__ __forceinline__ void x3_spread_piece(const X3Pipe& p, int c) {   // c folds to a constant in the unrolled passes
-#if X3_SPREAD
-    if (c < 1 || c >= X3_CPW || p.cp_ti >= p.n_tiles) return;
-    if (c == 1) x3_issue_piece<1>(p, p.cp_ti);
-    else if (c == 2) x3_issue_piece<2>(p, p.cp_ti);
-    else if (c == 3) x3_issue_piece<3>(p, p.cp_ti);
-    else if (c == 4) x3_issue_piece<4>(p, p.cp_ti);
-    else if (c == 5) x3_issue_piece<5>(p, p.cp_ti);
-    else if (c == 6) x3_issue_piece<6>(p, p.cp_ti);
-    else x3_issue_piece<7>(p, p.cp_ti);
-#endif
-}
-#if X3_STAGE
-static_assert(X3_CPW == 6 && X3_NBUF == 2 && X3_KT == 8, "register staging is written for 2 x 24 KB slots and four waves");
-template <int B>   // batch B (0 / 1) of slot p.cp_ti: pieces 3 B .. 3 B + 2 into the staging registers
-__device__ __forceinline__ void x3_stage_load(X3Pipe& p) {
-    if (p.cp_ti >= p.n_tiles) return;
-    const size_t toff = (size_t)(unsigned)__builtin_amdgcn_readfirstlane(p.cp_ti * X3_SLOT_BYTES + B * 3072);
-    const char* src = p.tiles + toff + p.goff;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) p.stg[c] = *reinterpret_cast<const u32x4_t*>(src + c * 1024);
-}
-template <int B>
-__device__ __forceinline__ void x3_stage_store(X3Pipe& p) {
-    if (p.cp_ti >= p.n_tiles) return;
-    char* dst = p.Bs + (p.cp_ti & 1) * X3_SLOT_BYTES + p.wave * (X3_SLOT_BYTES / X3_NW) + B * 3072 + (p.goff & 1023u);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4_t*>(dst + c * 1024) = p.stg[c];
-}
-// called behind the MFMAs of every triple with c = read-ahead index inside the slot: batch 0 was loaded in x3_next
-__device__ __forceinline__ void x3_stage_step(X3Pipe& p, int c) {
-    if (c == 3) { x3_stage_store<0>(p); x3_stage_load<1>(p); }
-    else if (c == 7) x3_stage_store<1>(p);
-}
-#endif
 // Make slot p.ti readable, start the copy of slot p.ti + X3_NBUF - 1 into the slot that p.ti - 1 just vacated, return the readable slot.
-// Before the barrier: my share of slot p.ti has landed and my fragment reads of slot p.ti - 1 are back.  FULL: issue every piece here
-// (a caller that does not run the triples of this slot); otherwise with X3_SPREAD only piece 0, the rest through x3_spread_piece.
-template <bool FULL = false>
+// Before the barrier: my share of slot p.ti has landed and my fragment reads of slot p.ti - 1 are back.
+// Not kept (measured, profiles/r03_i_x3_variants.txt): the pieces of the next slot issued one per triple instead of in a burst (2 001 vs
+// 1 205 us at 65 536 rows: an LDS-DMA between fragment reads costs more than the burst's queueing); the slot through registers
+// (global_load_dwordx4 + ds_write_b128 in two batches of three: 1 316 vs 1 191 us, 12 more live registers).
 __device__ __forceinline__ const char* x3_next(X3Pipe& p) {
 #ifdef X3_WAITS
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -168,14 +122,7 @@ __device__ __forceinline__ const char* x3_next(X3Pipe& p) {
 #if X3_ABL == 2
     if (p.cp_ti >= X3_NBUF) p.cp_ti = p.n_tiles;
 #endif
-#if X3_STAGE
-    x3_stage_load<0>(p);
-    if (FULL) { x3_stage_store<0>(p); x3_stage_load<1>(p); x3_stage_store<1>(p); }
-#else
-    if (p.cp_ti < p.n_tiles) {
-        if (FULL || !X3_SPREAD) x3_issue_tile(p, p.cp_ti); else x3_issue_piece<0>(p, p.cp_ti);
-    }
-#endif
+    if (p.cp_ti < p.n_tiles) x3_issue_tile(p, p.cp_ti);
 #ifdef X3_WAITS
     const unsigned long long t4 = __builtin_amdgcn_s_memtime();
     p.w_vm += t1 - t0; p.w_lgkm += t2 - t1; p.w_bar += t3 - t2; p.w_issue += t4 - t3;
@@ -353,11 +300,6 @@ __device__ __forceinline__ void x3_pass(X3Pipe& p, const f32x4* __restrict__ x, 
                 x3_frag(w[ga % D], base, ga % X3_KT);
             }
             acc[t] = x3_mfma6(w[g % D], xo, acc[t]);
-#if X3_STAGE
-            if (ga < NTRI) x3_stage_step(p, ga % X3_KT);
-#else
-            if (ga < NTRI) x3_spread_piece(p, ga % X3_KT);   // (ga % X3_KT == 0: piece 0 went out inside x3_next)
-#endif
             if (PIPE && t == 0 && kb + 1 < KB) xn = x3_split(src(2 * kb + 2), src(2 * kb + 3));
             __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);    // the three reads of the triple ahead first ...
             __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);    // ... then this triple's six MFMAs ...
@@ -393,13 +335,8 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
     int tr = 6; (void)tr;  // AR_TRACE: stamps 6.. = s_memtime of wave 0 after every pass / epilogue
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     X3Pipe p{reinterpret_cast<const char*>(a.tiles), Bs, 0, a.n_tiles * (X3_TRI / X3_KT), 0, wv, (unsigned)((wv * X3_CPW * 64 + lane) * 16)};
-#if X3_STAGE
-    p.cp_ti = 0;
-    x3_stage_load<0>(p); x3_stage_store<0>(p); x3_stage_load<1>(p); x3_stage_store<1>(p);
-#else
 #pragma unroll
     for (int s0 = 0; s0 < X3_NBUF - 1; ++s0) x3_issue_tile(p, s0);
-#endif
     const unsigned lane16 = lane * 16;
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -469,7 +406,7 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
         f32x4 s4[1] = {zero4};
         x3_pass<1, 8>(p, x, s4, lane16); AR_T();   // fc1 (256 -> 16): one tile
 #pragma unroll
-        for (int z = 0; z < X3_TRI / X3_KT; ++z) (void)x3_next<true>(p);   // + the all-zero tile behind it in the stream
+        for (int z = 0; z < X3_TRI / X3_KT; ++z) (void)x3_next(p);   // + the all-zero tile behind it in the stream
         const f32x4 b1 = *reinterpret_cast<const f32x4*>(sv + 4 * q);
         f32x4 yy[2];
 #pragma unroll

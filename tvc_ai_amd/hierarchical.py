@@ -78,17 +78,20 @@ class HierarchicalPolicy:
         return mean, ls, None
 
     def act(self, state: torch.Tensor, eps: Optional[torch.Tensor] = None, u: Optional[torch.Tensor] = None, clamp: bool = True,
-            share_rows: int = 0):
+            share_rows: int = 0, x3: bool = False):
         """select_goal + get_action + Normal sample in four launches' worth of host calls: -> (action, mean, log_std, goal_idx).
         share_rows = k > 0: rows [0, k) go through the one-launch acting kernel in its CU-sharing form (tvc_sac_act flags bit 2),
-        the rest in its whole-chip form, as VecTrainer does for the SAC policy."""
+        the rest in its whole-chip form, as VecTrainer does for the SAC policy.  x3 = True: the low-level policy's one-launch kernel on the
+        bf16 matrix pipe with split operands (fp32-exact, tvc_sac_act flags bit 4; >= 16 384 rows)."""
         sg = self._prepare(state.contiguous(), u)
         n = state.shape[0]
         if 0 < share_rows < n and not self.train_mode:
             out = tuple(torch.empty((n, self.action_dim), dtype=torch.float32, device=self.device) for _ in range(3))
             for lo, hi, sh in ((0, share_rows, True), (share_rows, n, False)):
-                self.low.act(sg[lo:hi], None if eps is None else eps[lo:hi], out=tuple(o[lo:hi] for o in out), clamp=clamp, share_cus=sh)
+                self.low.act(sg[lo:hi], None if eps is None else eps[lo:hi], out=tuple(o[lo:hi] for o in out), clamp=clamp, share_cus=sh,
+                             x3=x3)
             act, mean, ls = out
         else:
-            act, mean, ls = self.low.act(sg, eps, clamp=clamp, train_mode=self.train_mode, share_cus=share_rows >= n > 0)
+            act, mean, ls = self.low.act(sg, eps, clamp=clamp, train_mode=self.train_mode, share_cus=share_rows >= n > 0,
+                                         x3=x3 and not self.train_mode)
         return act, mean, ls, self._goal_idx[:n]

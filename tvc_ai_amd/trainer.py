@@ -202,7 +202,7 @@ class VecTrainer:
             self.u_goal.uniform_()
             # (the never-trained hierarchy has no snapshot to read; the update runs beside it)
             a, _, _, _ = self.hier.act(cur, self.eps_act, self.u_goal, clamp=self.safety is None,
-                                       share_rows=self.share_rows if share else 0)
+                                       share_rows=self.share_rows if share else 0, x3=self.acting_x3)
             raw.copy_(a)
         else:
             k = self.share_rows if share else self.n
