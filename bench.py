@@ -511,6 +511,22 @@ def x3_leg(args, device, n, K, W):
                          "fp32 accumulate; error against an fp64 evaluation equal to the f32-input MFMA kernel's (tests/test_acting_x3_gpu.py)",
            "kernel": x3_kernel_roofline(n, device)}
     t.close()
+    # ... and acting in TRAIN mode like the reference's get_action (Dropout live, attention unfolded: 1.9x the MFMA work) with the same
+    # arithmetic (actor_x3_kernel<true>), next to the f32 train-mode kernel (actor_split_kernel<true>): the reference-semantics figures
+    try:
+        tm = {}
+        for name, x3 in (("f32_mfma", False), ("split_operands", True)):
+            a3 = copy.copy(args)
+            a3.acting_x3, a3.acting_dropout = x3, True
+            r3 = trainer.bench_train(a3, 1, 0, device, n_envs=n)
+            dt3, _, _ = timed_steps(r3["step_fn"], min(K, 200), min(W, 30), 1, device, False)
+            k3 = min(K, 200)
+            tm[name] = {"value": n * k3 / dt3, "ms_per_step": dt3 / k3 * 1e3, "sac_updates_per_s": r3["trainer"].updates_per_step * k3 / dt3}
+            r3["trainer"].close()
+        rep["train_mode_acting"] = {**tm, "unit": "env-steps/s", "note": "VecTrainer(acting_dropout=True): tvc_sac_act flags bit 3 (+ bit 4), "
+                                                                        "masks element for element those of oracle/sac_torch.py: DropMasks"}
+    except Exception as e:
+        rep["train_mode_acting"] = {"error": f"{type(e).__name__}: {e}"}
     return rep
 
 

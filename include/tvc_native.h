@@ -262,7 +262,8 @@ int tvc_sac_enable_x3(tvc_sac* sac, void* stream);
  * the policy with fresh masks per call (needs family 0 and dropout_p > 0; per-layer kernels, attention not folded);
  * bit 4: split-operand arithmetic for the one-launch kernel (n >= 16 384 rows, reference shapes; ignored otherwise): every Linear on the
  * bf16 matrix pipe with both operands written as three bf16 terms and six products accumulated in fp32 -- the same fp32 result to
- * rounding (error against an fp64 sum equal to the f32-input MFMA's, tests/test_acting_x3_gpu.py) at 6 / 16 of its MFMA cycles.
+ * rounding (error against an fp64 sum equal to the f32-input MFMA's, tests/test_acting_x3_gpu.py) at 6 / 16 of its MFMA cycles.  With
+ * bit 3: the train-mode instantiation of that kernel (the net as trained, every Dropout live, the same masks as the other train-mode paths).
  * obs_dev float[n,obs]; act_dev float[n,A]; mean_dev / logstd_dev float[n,A] or NULL. */
 int tvc_sac_act(tvc_sac* sac, const float* obs_dev, int32_t n, const float* eps_dev, float* act_dev, float* mean_dev,
                 float* logstd_dev, int32_t flags, void* stream);

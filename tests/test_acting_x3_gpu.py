@@ -121,3 +121,51 @@ def test_train_loop_with_x3_acting_matches_the_f32_loop_on_its_first_step_and_st
     from tests import parity_log
     parity_log.record("train_loop_x3_first_step_action_diff", max_abs_diff=d, envs=n)
     tr.close()
+
+
+def _randomise_vectors(sac, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    for name, _, rows, cols in sac.table:
+        if name.startswith("policy.") and cols == 1:
+            sac.view(name).add_(0.1 * torch.randn(rows, device="cuda", generator=g))
+    sac.sync_derived()
+
+
+def test_train_mode_acting_with_split_operands_matches_the_restatement_mask_for_mask():
+    """actor_x3_kernel<true> (tvc_sac_act flags bits 3 + 4, >= 16 384 rows): the net as trained with every Dropout live, on the bf16 matrix
+    pipe with split operands.  Against the eager restatement with the kernels' own hash masks (DropMasks, site base 300, counter =
+    acting calls so far) element for element -- live parameters, snapshot, CU-sharing form -- and within rounding of the f32
+    train-mode kernel (actor_split_kernel<true>) at the same call index of an identical handle."""
+    from tvc_ai_amd.agent import NativeSAC, sac_cfg
+    from tests import parity_log
+    torch.set_num_threads(8)
+    n, p = 20000, 0.1
+    sacs = [NativeSAC(sac_cfg(0, batch_size=64, max_act_rows=32768, dropout_p=p), seed=23) for _ in range(2)]
+    for s_ in sacs:
+        _randomise_vectors(s_, 9)
+    sac, ref32 = sacs
+    P = sac.export_reference_state("policy")
+    g = torch.Generator().manual_seed(n)
+    obs = torch.randn(n, 10, generator=g) * 0.5
+    eps = torch.randn(n, 2, generator=g)
+    og, eg = obs.cuda(), eps.cuda()
+    masks = st.DropMasks(p, seed=int(sac.cfg.dropout_seed))
+    pick = torch.cat([torch.arange(0, 64), torch.randint(0, n, (400,), generator=g), torch.arange(n - 64, n)])
+    worst = worst32 = 0.0
+    sac.snapshot_policy()
+    for call, kw in enumerate((dict(), dict(snapshot=True), dict(snapshot=True, share_cus=True))):
+        act, mean, ls = sac.act(og, eg, train_mode=True, x3=True, **kw)
+        assert sac.act_counter() == call + 1
+        _, mean32, ls32 = ref32.act(og, eg, train_mode=True)  # same weights, same seed, same call index: the same masks
+        worst32 = max(worst32, float((mean - mean32).abs().max()), float((ls - ls32).abs().max()))
+        with torch.no_grad():
+            m_ref, ls_ref = st.actor_forward(P, obs, False, drop=masks.hook(call, 300))
+        a_ref = torch.clamp(m_ref + torch.exp(ls_ref) * eps, -1, 1)
+        for got, want in ((mean, m_ref), (ls, ls_ref), (act, a_ref)):
+            err = (got.cpu()[pick] - want[pick]).abs().max().item()
+            worst = max(worst, err)
+            assert err <= 3e-4 * max(1.0, want.abs().max().item()), (call, kw, err)
+    assert worst32 <= 1e-4, worst32
+    parity_log.record("train_mode_acting_x3_n20000", rows=n, calls=3, worst_abs_err=worst, worst_vs_f32_train_kernel=worst32)
+    for s_ in sacs:
+        s_.close()

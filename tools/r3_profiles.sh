@@ -57,6 +57,7 @@ run --workload train --envs-per-gpu 16384 --steps 300 --warmup 30 --acting-x3
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --acting-x3 --updates-per-step 2
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --acting-x3 --updates-per-step 4
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --acting-dropout
+run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --acting-dropout --acting-x3
 run --workload train --envs-per-gpu 4096 --steps 300 --warmup 30 --acting-dropout --segments on
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --updates-per-step 2
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --updates-per-step 4

@@ -615,14 +615,17 @@ struct PackSet3 { const PackTile3* tiles; int n_tiles; char* out; };
 // up to three streams per launch: the acting net (attention and embedding folded), when train-mode acting is live the net as trained,
 // and when split-operand acting is live the folded net again as bf16 triples
 __global__ void __launch_bounds__(256) pack_actor_kernel(const float* __restrict__ P, const float* __restrict__ OV, PackSet s0, PackSet s1,
-                                                         HeadPack hp, Ticks tk, PackSet3 s3) {
+                                                         HeadPack hp, Ticks tk, PackSet3 s3, PackSet3 s4) {
     __shared__ float red[2][4][256];
     int b = blockIdx.x;
     const int tid = threadIdx.x;
     const int n0 = s0.n_tiles + s0.n_vecs, n1 = s1.n_tiles + s1.n_vecs;
     if (b > n0 + n1) {  // behind the head's workgroup: the split-operand stream (when it is live), one 24 KB tile per workgroup
-        const int i = b - (n0 + n1 + 1);
-        pack_x3_tile(s3.tiles[i], P, OV, reinterpret_cast<u32x4_t*>(s3.out + (size_t)i * X3_TILE_BYTES));
+        int i = b - (n0 + n1 + 1);
+        const bool fourth = i >= s3.n_tiles;   // ... and of the net as trained (train-mode acting with the split-operand kernel)
+        if (fourth) i -= s3.n_tiles;
+        const PackSet3& sx = fourth ? s4 : s3;
+        pack_x3_tile(sx.tiles[i], P, OV, reinterpret_cast<u32x4_t*>(sx.out + (size_t)i * X3_TILE_BYTES));
         return;
     }
     if (b == n0 + n1) {  // last workgroup: the folded output head (+ the riders of this launch)

@@ -22,6 +22,7 @@
 // k-blocks outer, n-tiles inner, so one split of the activation block feeds 6 MFMAs on each of the pass's n-tiles.
 #pragma once
 #include "tvc_actor_rows.h"
+#include "tvc_actor_split.h"   // AsDrop: the counter-hash dropout masks of train-mode acting
 
 namespace tvcnn {
 
@@ -310,6 +311,10 @@ __device__ __forceinline__ void x3_pass(X3Pipe& p, const f32x4* __restrict__ x, 
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// TRAIN = false: the deterministic net with the attention and the embedding folded (stream of rows_tables_x3()).
+// TRAIN = true : the net as trained, Dropout live at every site like the reference's get_action (agent/...:765; stream of
+//                rows_tables_x3_train(), masks = AsDrop's counter hash, element for element those of the per-layer path and of DropMasks)
+template <bool TRAIN>
 #if X3_NW == 4
 __global__ void __launch_bounds__(256, 2) actor_x3_kernel(ActRowsArgs a) {
 #else
@@ -349,18 +354,50 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
         xin[r] = k < a.obs_dim ? v : 0.0f;
     }
     const float* vec = a.vec;
+    const float* __restrict__ tvec = a.tvec;
+    AsDrop dr{};
+    if (TRAIN) {
+        dr.ctr = (unsigned)*a.drop_ctr; dr.seed = a.drop_seed; dr.thresh = a.drop_thresh; dr.scale = a.drop_scale;
+        dr.rowmix = drop_mix((unsigned)row + 0x632BE5ABu);
+    }
     f32x4 x[16];
-    {   // layer 0, first sublayer: embedding + PE(0) + folded attention + residual as ONE obs -> 256 Linear (two tiles), then norm1
+    if (!TRAIN) {   // layer 0, first sublayer: embedding + PE(0) + folded attention + residual as ONE obs -> 256 Linear (two tiles), then norm1
         ar_zero<16>(x);
         const f32x4 xin2[2] = {xin, zero4};
         x3_pass<16, 1>(p, xin2, x, lane16); AR_T();
 #pragma unroll
         for (int t = 0; t < 16; ++t) x[t] += ar_vec4(vec, t, q);
         x3_layernorm<16>(x, vec + 256, vec + 512, q); AR_T();
+    } else {        // x = W_e obs + b_e + PE(0)   (agent/...:196-203)
+        ar_zero<16>(x);
+        const f32x4 xin2[2] = {xin, zero4};
+        x3_pass<16, 1>(p, xin2, x, lane16); AR_T();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) x[t] += ar_vec4(tvec, t, q) + ar_vec4(a.pe0, t, q);
     }
     for (int l = 0; l < a.n_layers; ++l) {
         const float* lv = vec + l * AR_LAYER_VEC;
-        if (l > 0) {  // x = norm1(x + W_ov x + b_ov)
+        if (TRAIN) {
+            // self-attention at sequence length 1 = out_proj(dropout_heads(v_proj(x))): the attention-weight dropout zeroes / rescales whole
+            // heads of V (32 columns = two tiles each); then dropout1, residual, norm1
+            const float* tl = tvec + 256 + 512 * l;
+            const unsigned kv = dr.key(1 + 6 * l), ko = dr.key(2 + 6 * l);
+            f32x4 v[16];
+            ar_zero<16>(v);
+            x3_pass<16, 8>(p, x, v, lane16); AR_T();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[t] = (v[t] + ar_vec4(tl, t, q)) * dr.f(kv, (unsigned)(t >> 1));
+            f32x4 o[16];
+            ar_zero<16>(o);
+            x3_pass<16, 8, false>(p, v, o, lane16); AR_T();
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                o[t] += ar_vec4(tl + 256, t, q);
+                dr.tile(ko, t, q, o[t]);
+                x[t] += o[t];
+            }
+            x3_layernorm<16>(x, lv + 256, lv + 512, q); AR_T();
+        } else if (l > 0) {  // x = norm1(x + W_ov x + b_ov)
             f32x4 acc[16];
             ar_zero<16>(acc);
             x3_pass<16, 8>(p, x, acc, lane16); AR_T();
@@ -391,17 +428,23 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[t][r] = x3_gelu(h[t][r] + b4[r]);
 #endif
+                if (TRAIN) dr.tile(dr.key(4 + 6 * l), 8 * quarter + t, q, h[t]);  // the FFN's dropout (hidden units 128 quarter + ...)
             }
             AR_T();
             x3_pass<16, 4>(p, h, acc2, lane16); AR_T();
         }
+        const unsigned k2 = TRAIN ? dr.key(5 + 6 * l) : 0u;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) x[t] += acc2[t] + ar_vec4(lv + 1280, t, q);
+        for (int t = 0; t < 16; ++t) {
+            f32x4 y = acc2[t] + ar_vec4(lv + 1280, t, q);
+            if (TRAIN) dr.tile(k2, t, q, y);  // dropout2
+            x[t] += y;
+        }
         x3_layernorm<16>(x, lv + 1536, lv + 1792, q); AR_T();
     }
     const float* tv = vec + a.n_layers * AR_LAYER_VEC;
     x3_layernorm<16>(x, tv, tv + 256, q); AR_T();  // feature_norm
-    if (a.use_se) {  // x *= sigmoid(fc2(relu(fc1(x))))
+    if (!TRAIN && a.use_se) {  // x *= sigmoid(fc2(relu(fc1(x))))
         const float* sv = tv + AR_TAIL_VEC;
         f32x4 s4[1] = {zero4};
         x3_pass<1, 8>(p, x, s4, lane16); AR_T();   // fc1 (256 -> 16): one tile
@@ -439,11 +482,20 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
         if ((t & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
     x3_layernorm<32>(pp, tv + 1024, tv + 1536, q); AR_T();
+    if (TRAIN) {  // Dropout behind policy_head.2
+        const unsigned k3 = dr.key(3 + 6 * a.n_layers);
+#pragma unroll
+        for (int t = 0; t < 32; ++t) dr.tile(k3, t, q, pp[t]);
+    }
     f32x4* park = Park + tid;
 #pragma unroll
     for (int i = 0; i < X3_PARK; ++i) park[i * (64 * X3_NW)] = pp[32 - X3_PARK + i];
     // ---- 512 -> 512 GELU LayerNorm -> 2A outputs, the LayerNorm + output Linear folded into running sums (see actor_rows_kernel)
-    float s1 = 0.0f, s2 = 0.0f, d[4] = {0.f, 0.f, 0.f, 0.f};
+    // TRAIN: Dropout behind policy_head.6 sits between the folded LayerNorm and the output Linear,
+    //   out[o] = rstd (sum_n m_n g_n gW[o][n] - mean sum_n m_n gW[o][n]) + sum_n m_n bW[o][n] + b8[o]      (see actor_split_kernel)
+    float s1 = 0.0f, s2 = 0.0f, d[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {0.f, 0.f, 0.f, 0.f}, em[4] = {0.f, 0.f, 0.f, 0.f};
+    const unsigned k6 = TRAIN ? dr.key(5 + 6 * a.n_layers) : 0u;
+    const float* bw = TRAIN ? tvec + 256 + 512 * a.n_layers : nullptr;  // bW[o][n] = beta6[n] W8[o][n], then b8[4]
     // policy_head.4 in X3_HQ output slices of 16 * HN features (4 quarters: 32 accumulators instead of 64 beside the 96 + 32 parked
     // registers of the activation -- with halves hipcc kept 24 activation tiles in scratch and reloaded each behind a fresh tile copy)
     constexpr int HN = 32 / X3_HQ;
@@ -459,31 +511,42 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
             f32x4 gw[4];
 #pragma unroll
             for (int o = 0; o < 4; ++o) gw[o] = ar_vec4(tv + 3584 + 512 * o, tt, q);
+            f32x4 bwv[4];
+            if (TRAIN) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) bwv[o] = ar_vec4(bw + 512 * o, tt, q);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = x3_gelu(a2[t][r] + b4[r]);
                 s1 += v;
                 s2 = fmaf(v, v, s2);
+                const float m = TRAIN ? dr.f(k6, (unsigned)(16 * tt + 4 * q + r)) : 1.0f;
 #pragma unroll
-                for (int o = 0; o < 4; ++o) d[o] = fmaf(v, gw[o][r], d[o]);
+                for (int o = 0; o < 4; ++o) {
+                    d[o] = fmaf(v * m, gw[o][r], d[o]);
+                    if (TRAIN) { gm[o] = fmaf(m, gw[o][r], gm[o]); em[o] = fmaf(m, bwv[o][r], em[o]); }
+                }
             }
             if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (keeps the vector loads of four tiles, not sixteen, in flight)
         }
         // a slice's epilogue must not sink into the next slice's pass (hipcc moves it towards the use of its sums, behind that
         // pass: its accumulators live beside the next ones, the hoisted vector loads spilled, every reload a vmcnt(0) behind a fresh copy)
         asm volatile("" : "+v"(s1), "+v"(s2), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+        if (TRAIN) asm volatile("" : "+v"(gm[0]), "+v"(gm[1]), "+v"(gm[2]), "+v"(gm[3]), "+v"(em[0]), "+v"(em[1]), "+v"(em[2]), "+v"(em[3]));
         __builtin_amdgcn_sched_barrier(0);
     }
 #define X3_RED(v) v += __shfl_xor(v, 16); v += __shfl_xor(v, 32)
     X3_RED(s1); X3_RED(s2);
 #pragma unroll
-    for (int o = 0; o < 4; ++o) { X3_RED(d[o]); }
+    for (int o = 0; o < 4; ++o) { X3_RED(d[o]); if (TRAIN) { X3_RED(gm[o]); X3_RED(em[o]); } }
 #undef X3_RED
     const float mean = s1 * (1.0f / 512.0f);
     const float rstd = rsqrtf(fmaxf(s2 * (1.0f / 512.0f) - mean * mean, 0.0f) + 1e-5f);
     float out[4];
 #pragma unroll
-    for (int o = 0; o < 4; ++o) out[o] = rstd * (d[o] - mean * tv[5636 + o]) + tv[5632 + o];
+    for (int o = 0; o < 4; ++o)
+        out[o] = TRAIN ? rstd * (d[o] - mean * gm[o]) + em[o] + bw[2048 + o] : rstd * (d[o] - mean * tv[5636 + o]) + tv[5632 + o];
     if (a.stamps && tid == 0) {
         a.stamps[AR_STAMPS * blockIdx.x + 2] = __builtin_amdgcn_s_memtime();
         a.stamps[AR_STAMPS * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();

@@ -972,6 +972,10 @@ struct tvc_sac {
     int x3_tiles = 0;
     char *xpack = nullptr, *snap_xpack = nullptr;  // [x3_tiles * 24 KB]; the vector section is `pack`'s
     PackTile3* d_xtiles = nullptr;
+    bool x3t_live = false, x3t_attr_set = false;   // ... and of the net as trained (train-mode acting, flags bits 3 + 4)
+    int x3t_tiles = 0;
+    char *xtpack = nullptr, *snap_xtpack = nullptr;
+    PackTile3* d_xttiles = nullptr;
     float* tq = nullptr;                          // [2, B]: output of the target critics (read by q_loss_kernel)
     bool tick_pending = false;                    // the critics' Adam clock is one step behind: its advance rides on the next
                                                   // launch of the chain (tvc_sac_actor_grads), or is flushed by whoever needs it
@@ -1087,6 +1091,32 @@ static void rows_tables_x3(const tvc_sac_cfg& c, const NetDef& actor, const Fold
     for (int half = 0; half < 2; ++half) pass(off("policy_head.0.weight"), d, 256 * half, 0, 16, 8, d, d, 0);
     for (int part = 0; part < X3_HQ; ++part)
         pass(off("policy_head.4.weight"), 512, (512 / X3_HQ) * part, 0, 32 / X3_HQ, 16, 512, 512 / X3_HQ, 0);
+}
+
+static void rows_tables_x3_train(const tvc_sac_cfg& c, const NetDef& actor, std::vector<PackTile3>& tiles) {
+    auto off = [&](const std::string& name) -> long {
+        for (const TensorInfo& t : actor.tensors)
+            if (t.name == name) return t.off;
+        return -1;
+    };
+    const int d = 256;
+    auto pass = [&](long src, int ld, int n0, int k0, int NT, int KB, int kvalid, int nvalid) {
+        for (int g0 = 0; g0 < NT * KB; g0 += X3_TRI)
+            tiles.push_back(PackTile3{src < 0 ? -1 : src + (long)n0 * ld, ld, k0, kvalid, nvalid, g0, NT, 0});
+    };
+    pass(off("input_embedding.weight"), c.obs_dim, 0, 0, 16, 1, c.obs_dim, d);
+    for (int l = 0; l < c.n_layers; ++l) {
+        const std::string p = "layers." + std::to_string(l) + ".";
+        pass(off(p + "v_proj.weight"), d, 0, 0, 16, 8, d, d);
+        pass(off(p + "out_proj.weight"), d, 0, 0, 16, 8, d, d);
+        for (int quarter = 0; quarter < 4; ++quarter) {
+            pass(off(p + "linear1.weight"), d, 128 * quarter, 0, 8, 8, d, 128);
+            pass(off(p + "linear2.weight"), 512, 0, 128 * quarter, 16, 4, 512, d);
+        }
+    }
+    for (int half = 0; half < 2; ++half) pass(off("policy_head.0.weight"), d, 256 * half, 0, 16, 8, d, d);
+    for (int part = 0; part < X3_HQ; ++part)
+        pass(off("policy_head.4.weight"), 512, (512 / X3_HQ) * part, 0, 32 / X3_HQ, 16, 512, 512 / X3_HQ);
 }
 
 // Train-mode stream: embedding (one tile), then per encoder layer v_proj (16 tiles), out_proj (16), the FFN as in rows_tables(),
@@ -1300,6 +1330,16 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
         h->tpack_floats = (long)h->trows_tiles * 4096 + train_vec_floats(*cfg);
         bytes += 2 * h->tpack_floats * 4 + tptiles.size() * sizeof(PackTile) + tpvecs.size() * sizeof(PackVec) + 2048;
     }
+    std::vector<PackTile3> xttiles;
+    if (h->train_rows_ok) {
+        rows_tables_x3_train(*cfg, h->actor, xttiles);
+        bool ok = true;
+        for (const PackTile3& t : xttiles) ok = ok && t.src >= 0;
+        if (ok) {
+            h->x3t_tiles = (int)xttiles.size();
+            bytes += 2L * h->x3t_tiles * X3_TILE_BYTES + xttiles.size() * sizeof(PackTile3) + 2048;
+        }
+    }
     hipError_t he = hipMalloc(&h->slab, bytes);
     if (he != hipSuccess) {
         delete h;
@@ -1345,6 +1385,11 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
         h->snap_tpack = (float*)carve(p, h->tpack_floats * 4);
         h->d_tptiles = (PackTile*)carve(p, tptiles.size() * sizeof(PackTile));
         h->d_tpvecs = (PackVec*)carve(p, tpvecs.size() * sizeof(PackVec));
+        if (h->x3t_tiles > 0) {
+            h->xtpack = carve(p, (long)h->x3t_tiles * X3_TILE_BYTES);
+            h->snap_xtpack = carve(p, (long)h->x3t_tiles * X3_TILE_BYTES);
+            h->d_xttiles = (PackTile3*)carve(p, xttiles.size() * sizeof(PackTile3));
+        }
     }
     if ((long)(p - (char*)h->slab) > bytes) {
         (void)hipFree(h->slab);
@@ -1371,6 +1416,8 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
         if (he == hipSuccess && h->train_rows_ok) {
             he = hipMemcpy(h->d_tptiles, tptiles.data(), tptiles.size() * sizeof(PackTile), hipMemcpyHostToDevice);
             if (he == hipSuccess) he = hipMemcpy(h->d_tpvecs, tpvecs.data(), tpvecs.size() * sizeof(PackVec), hipMemcpyHostToDevice);
+            if (he == hipSuccess && h->x3t_tiles > 0)
+                he = hipMemcpy(h->d_xttiles, xttiles.data(), xttiles.size() * sizeof(PackTile3), hipMemcpyHostToDevice);
         }
         if (he != hipSuccess) {
             (void)hipFree(h->slab);
@@ -1398,6 +1445,8 @@ void tvc_sac_destroy(tvc_sac* h) {
     delete h;
 }
 
+static const float* P_head(tvc_sac* h, int k) { return h->P_actor() + h->head_off[k]; }
+
 // Split-operand acting stream (tvc_actor_x3.h): packed from the folded weights the last update left, then re-packed by every policy
 // update and copied by every snapshot.  Idempotent; stream-ordered (call it where no update runs on another stream).
 static int x3_make_live(tvc_sac* h, hipStream_t st) {
@@ -1409,7 +1458,7 @@ static int x3_make_live(tvc_sac* h, hipStream_t st) {
                 h->pack + (long)h->rows_tiles * 4096 + (long)h->cfg.n_layers * AR_LAYER_VEC, nullptr};
     PackSet none{nullptr, 0, nullptr, 0, nullptr, nullptr};
     hipLaunchKernelGGL(pack_actor_kernel, dim3(1 + h->x3_tiles), dim3(256), 0, st, P, h->ov, none, none, hp,
-                       Ticks{nullptr, 0.f, 0.f, nullptr}, PackSet3{h->d_xtiles, h->x3_tiles, h->xpack});
+                       Ticks{nullptr, 0.f, 0.f, nullptr}, PackSet3{h->d_xtiles, h->x3_tiles, h->xpack}, PackSet3{nullptr, 0, nullptr});
     // (a snapshot taken before this stream existed holds the same parameters unless an update ran in between)
     TVC_HIP_CHECK(hipMemcpyAsync(h->snap_xpack, h->xpack, (size_t)h->x3_tiles * X3_TILE_BYTES, hipMemcpyDeviceToDevice, st));
     TVC_HIP_CHECK(hipGetLastError());
@@ -1447,7 +1496,7 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
                 PackSet s1{h->d_tptiles, h->trows_tiles, h->d_tpvecs, h->trows_vecs, reinterpret_cast<float4*>(h->tpack),
                            h->tpack + (long)h->trows_tiles * 4096};
                 hipLaunchKernelGGL(pack_actor_kernel, dim3(s1.n_tiles + s1.n_vecs + 1), dim3(256), 0, st, P, h->ov, none, s1, hp,
-                                   Ticks{nullptr, 0.f, 0.f, nullptr}, PackSet3{nullptr, 0, nullptr});
+                                   Ticks{nullptr, 0.f, 0.f, nullptr}, PackSet3{nullptr, 0, nullptr}, PackSet3{nullptr, 0, nullptr});
                 // (the snapshot, if one is being read, was taken before this stream existed: it holds the same parameters)
                 TVC_HIP_CHECK(hipMemcpyAsync(h->snap_tpack, h->tpack, h->tpack_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
             }
@@ -1462,6 +1511,35 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
             a.drop_ctr = h->act_ctr; a.drop_thresh = (unsigned)lroundf(h->cfg.dropout_p * 65536.0f);
             a.drop_scale = 65536.0f / (float)(65536u - a.drop_thresh); a.drop_seed = h->cfg.dropout_seed;
             size_t dyn_lds = 0;
+            if ((flags & 16) && h->x3t_tiles > 0 && n >= rows_min_rows()) {
+                // ... from 16 384 rows with bit 4: the row-owner kernel on the bf16 matrix pipe (actor_x3_kernel<true>) on the same net's
+                // split-operand stream; the vector sections are the ones above
+                if (!h->x3t_live) {
+                    h->x3t_live = true;
+                    PackSet none{nullptr, 0, nullptr, 0, nullptr, nullptr};
+                    HeadPack hp{P_head(h, 0), P_head(h, 1), P_head(h, 2), P_head(h, 3), 2 * A,
+                                h->pack + (long)h->rows_tiles * 4096 + (long)h->cfg.n_layers * AR_LAYER_VEC,
+                                h->tpack + (long)h->trows_tiles * 4096 + 256 + 512L * h->cfg.n_layers};
+                    hipLaunchKernelGGL(pack_actor_kernel, dim3(1 + h->x3t_tiles), dim3(256), 0, st, h->P_actor(), h->ov, none, none, hp,
+                                       Ticks{nullptr, 0.f, 0.f, nullptr}, PackSet3{nullptr, 0, nullptr},
+                                       PackSet3{h->d_xttiles, h->x3t_tiles, h->xtpack});
+                    TVC_HIP_CHECK(hipMemcpyAsync(h->snap_xtpack, h->xtpack, (size_t)h->x3t_tiles * X3_TILE_BYTES, hipMemcpyDeviceToDevice, st));
+                }
+                a.tiles = reinterpret_cast<const float4*>(snap ? h->snap_xtpack : h->xtpack);
+                a.n_tiles = h->x3t_tiles;
+                if (flags & 4) {
+                    if (!h->x3t_attr_set) {
+                        TVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(actor_x3_kernel<true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+                        h->x3t_attr_set = true;
+                    }
+                    dyn_lds = 65536;
+                }
+                hipLaunchKernelGGL(actor_x3_kernel<true>, dim3((n + 16 * X3_NW - 1) / (16 * X3_NW)), dim3(64 * X3_NW), dyn_lds, st, a);
+                hipLaunchKernelGGL(act_ctr_tick_kernel, dim3(1), dim3(1), 0, st, h->act_ctr);  // every workgroup has read the counter
+                TVC_HIP_CHECK(hipGetLastError());
+                return 0;
+            }
             if (flags & 4) {
                 if (!h->tsplit_attr_set) {
                     TVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(actor_split_kernel<true>),
@@ -1498,13 +1576,13 @@ int tvc_sac_act(tvc_sac* h, const float* obs, int32_t n, const float* eps, float
         size_t dyn_lds = 0;
         if (flags & 4) {  // "share the CUs": 48 KB static + 64 KB unused dynamic LDS -> one workgroup per CU instead of two
             if (!h->x3_attr_set) {
-                TVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(actor_x3_kernel),
+                TVC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(actor_x3_kernel<false>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
                 h->x3_attr_set = true;
             }
             dyn_lds = 65536;
         }
-        hipLaunchKernelGGL(actor_x3_kernel, dim3((n + 16 * X3_NW - 1) / (16 * X3_NW)), dim3(64 * X3_NW), dyn_lds, st, a);
+        hipLaunchKernelGGL(actor_x3_kernel<false>, dim3((n + 16 * X3_NW - 1) / (16 * X3_NW)), dim3(64 * X3_NW), dyn_lds, st, a);
         TVC_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -1792,8 +1870,9 @@ static void refresh_folded(tvc_sac* h, hipStream_t st, AdamClock* tick) {
         PackSet s1{h->d_tptiles, tl ? h->trows_tiles : 0, h->d_tpvecs, tl ? h->trows_vecs : 0,
                    reinterpret_cast<float4*>(h->tpack), tl ? h->tpack + (long)h->trows_tiles * 4096 : nullptr};
         const PackSet3 s3{h->d_xtiles, h->x3_live ? h->x3_tiles : 0, h->xpack};
-        hipLaunchKernelGGL(pack_actor_kernel, dim3(s0.n_tiles + s0.n_vecs + s1.n_tiles + s1.n_vecs + 1 + s3.n_tiles), dim3(256), 0, st,
-                           h->P_actor(), h->ov, s0, s1, hp, tk, s3);
+        const PackSet3 s4{h->d_xttiles, h->x3t_live ? h->x3t_tiles : 0, h->xtpack};
+        hipLaunchKernelGGL(pack_actor_kernel, dim3(s0.n_tiles + s0.n_vecs + s1.n_tiles + s1.n_vecs + 1 + s3.n_tiles + s4.n_tiles), dim3(256),
+                           0, st, h->P_actor(), h->ov, s0, s1, hp, tk, s3, s4);
     }
 }
 
@@ -1856,6 +1935,8 @@ int tvc_sac_snapshot_policy(tvc_sac* h, void* stream) {
         TVC_HIP_CHECK(hipMemcpyAsync(h->snap_tpack, h->tpack, h->tpack_floats * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (h->x3_live)
         TVC_HIP_CHECK(hipMemcpyAsync(h->snap_xpack, h->xpack, (size_t)h->x3_tiles * X3_TILE_BYTES, hipMemcpyDeviceToDevice, st));
+    if (h->x3t_live)
+        TVC_HIP_CHECK(hipMemcpyAsync(h->snap_xtpack, h->xtpack, (size_t)h->x3t_tiles * X3_TILE_BYTES, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 

@@ -80,8 +80,9 @@ class VecTrainer:
         self.acting_dropout = bool(acting_dropout) and self.dropout_p > 0.0
         # acting_x3 = True: the one-launch acting kernel (>= 16 384 rows) runs on the bf16 matrix pipe with three-term split operands,
         # fp32-exact (tvc_actor_x3.h, tvc_sac_act flags bit 4); its weight stream is packed now, before any update can run beside it
-        self.acting_x3 = bool(acting_x3) and family == 0 and not self.acting_dropout
-        if self.acting_x3:
+        # (with acting_dropout: the train-mode instantiation of the same kernel on the stream of the net as trained, flags bits 3 + 4)
+        self.acting_x3 = bool(acting_x3) and family == 0
+        if self.acting_x3 and not self.acting_dropout:
             self.sac.enable_x3()
         # intrinsic curiosity bonus of the reference's training env (scripts/train.py:318, env/...:496-502)
         self.curiosity = None
@@ -103,6 +104,11 @@ class VecTrainer:
         self.obs = [torch.empty((n, 10), device=d), torch.empty((n, 10), device=d)]
         self.cur = 0
         self.act = torch.empty((n, 2), device=d)
+        if self.acting_x3 and self.acting_dropout and n >= 16384:
+            # pack the train-mode streams now, before an update can run beside the first acting call (one throw-away call on zeros)
+            z = torch.zeros((n, 10), device=d)
+            self.sac.act(z, None, train_mode=True, x3=True)
+            del z
         self.mean = torch.empty((n, 2), device=d)
         self.ls = torch.empty((n, 2), device=d)
         self.eps_act = torch.empty((n, 2), device=d)
