@@ -377,6 +377,10 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
     }
     for (int l = 0; l < a.n_layers; ++l) {
         const float* lv = vec + l * AR_LAYER_VEC;
+        // (the masks' column terms (c >> 1) * K depend on the lane quarter only: hipcc hoists all of them out of the layer loop, ~60
+        // registers it then spills in the prologue and reloads behind tile copies; an opaque copy of q per layer keeps them local)
+        int qd = q;
+        if (TRAIN) asm volatile("" : "+v"(qd));
         if (TRAIN) {
             // self-attention at sequence length 1 = out_proj(dropout_heads(v_proj(x))): the attention-weight dropout zeroes / rescales whole
             // heads of V (32 columns = two tiles each); then dropout1, residual, norm1
@@ -387,14 +391,20 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
             x3_pass<16, 8>(p, x, v, lane16); AR_T();
 #pragma unroll
             for (int t = 0; t < 16; ++t) v[t] = (v[t] + ar_vec4(tl, t, q)) * dr.f(kv, (unsigned)(t >> 1));
+            // x (64 registers), V (64) and out_proj's accumulators (64) would be live together: the upper half of x waits in the head's
+            // LDS parking area (idle until the head) while out_proj runs
+            f32x4* xpark = Park + tid;
+#pragma unroll
+            for (int t = 0; t < X3_PARK; ++t) xpark[t * (64 * X3_NW)] = x[16 - X3_PARK + t];
             f32x4 o[16];
             ar_zero<16>(o);
             x3_pass<16, 8, false>(p, v, o, lane16); AR_T();
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 o[t] += ar_vec4(tl + 256, t, q);
-                dr.tile(ko, t, q, o[t]);
-                x[t] += o[t];
+                dr.tile(ko, t, qd, o[t]);
+                if (t >= 16 - X3_PARK) x[t] = xpark[(t - (16 - X3_PARK)) * (64 * X3_NW)] + o[t];
+                else x[t] += o[t];
             }
             x3_layernorm<16>(x, lv + 256, lv + 512, q); AR_T();
         } else if (l > 0) {  // x = norm1(x + W_ov x + b_ov)
@@ -428,7 +438,7 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[t][r] = x3_gelu(h[t][r] + b4[r]);
 #endif
-                if (TRAIN) dr.tile(dr.key(4 + 6 * l), 8 * quarter + t, q, h[t]);  // the FFN's dropout (hidden units 128 quarter + ...)
+                if (TRAIN) dr.tile(dr.key(4 + 6 * l), 8 * quarter + t, qd, h[t]);  // the FFN's dropout (hidden units 128 quarter + ...)
             }
             AR_T();
             x3_pass<16, 4>(p, h, acc2, lane16); AR_T();
@@ -437,7 +447,7 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             f32x4 y = acc2[t] + ar_vec4(lv + 1280, t, q);
-            if (TRAIN) dr.tile(k2, t, q, y);  // dropout2
+            if (TRAIN) dr.tile(k2, t, qd, y);  // dropout2
             x[t] += y;
         }
         x3_layernorm<16>(x, lv + 1536, lv + 1792, q); AR_T();
@@ -484,8 +494,10 @@ __global__ void __launch_bounds__(64 * X3_NW) actor_x3_kernel(ActRowsArgs a) {
     x3_layernorm<32>(pp, tv + 1024, tv + 1536, q); AR_T();
     if (TRAIN) {  // Dropout behind policy_head.2
         const unsigned k3 = dr.key(3 + 6 * a.n_layers);
+        int qd = q;
+        asm volatile("" : "+v"(qd));
 #pragma unroll
-        for (int t = 0; t < 32; ++t) dr.tile(k3, t, q, pp[t]);
+        for (int t = 0; t < 32; ++t) dr.tile(k3, t, qd, pp[t]);
     }
     f32x4* park = Park + tid;
 #pragma unroll
