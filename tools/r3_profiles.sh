@@ -63,6 +63,7 @@ run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --updates-per-
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --updates-per-step 4
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --dr-stage 0
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --shipped-acting
+run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --shipped-acting --acting-x3
 run --workload train --envs-per-gpu 65536 --steps 300 --warmup 30 --family 1
 run --workload train --envs-per-gpu 4096 --steps 300 --warmup 30 --family 1 --segments on
 run --workload physics --envs-per-gpu 65536 --steps 2000 --warmup 100

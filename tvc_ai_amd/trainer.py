@@ -59,6 +59,10 @@ class VecTrainer:
         self.share_rows = num_envs
         if self.share_cus and updates_per_step <= 1 and num_envs >= 32768 and (num_envs // 2) % 64 == 0:
             self.share_rows = num_envs // 2
+        if acting_x3 and family == 0 and updates_per_step <= 1 and num_envs >= 16384:
+            # the split-operand kernel at one workgroup per CU (one wave per SIMD) is in its bad regime: by default every row takes the
+            # exclusive form and the update follows it (65 536 envs: 1.69 ms with 0 shared rows, 1.66 with 16 384, 2.02 with 32 768)
+            self.share_rows = 0
         if share_rows is not None:  # explicit split (bench: chosen at warm-up by tune_share_rows, identically on every rank)
             self.share_rows = max(0, min(int(share_rows), num_envs))
         self.share_tuning = None
