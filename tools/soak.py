@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak run of the vector train loop: many steps with domain randomisation + curiosity, then checks that nothing drifted
-(finite parameters and losses, bounded replay rewards, stable device memory).  usage: python3 tools/soak.py [steps] [envs]"""
+(finite parameters and losses, bounded replay rewards, stable device memory).  usage: python3 tools/soak.py [steps] [envs] [x3=0|1] [dropout=0|1]
+x3 = 1: the acting pass on the split-operand kernel (VecTrainer(acting_x3=True)); dropout = 1: acting in train mode"""
 import os
 import sys
 import time
@@ -13,8 +14,10 @@ from tvc_ai_amd.trainer import VecTrainer
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 envs = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+x3 = len(sys.argv) > 3 and sys.argv[3] == "1"
+drop = len(sys.argv) > 4 and sys.argv[4] == "1"
 tr = VecTrainer(envs, device="cuda:0", family=0, batch_size=256, replay_capacity=1_000_000, seed=7, enable_curiosity=True,
-                **dr_from_yaml({}, 5))
+                acting_x3=x3, acting_dropout=drop, defer_join=True, **dr_from_yaml({}, 5))
 for _ in range(50):
     tr.step(True)
 torch.cuda.synchronize()
