@@ -22,7 +22,7 @@ for r in csv.DictReader(open(src)):
 calls = {r["Name"]: (int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(src))}
 steps = next((c for k, (c, _) in calls.items() if "update_prep_kernel" in k), None)
 for k in ("tvcnn::actor_rows_kernel", "tvcnn::actor_x3_kernel"):
-    full = next((n for n in calls if n.startswith(k)), None)
+    full = next((n for n in calls if n.startswith(k) or n.startswith("void " + k)), None)  # (template instantiations carry the return type)
     if steps and full and calls[full][0] > steps:
         rows[k + " [average of one launch]"] = rows[k]
         rows[k] = calls[full][1] / 1e3 / steps
