@@ -112,13 +112,17 @@ struct DropArgs {
     float scale;
     int group;        // columns sharing one mask element: 1 = elementwise, d_model / nhead = one per attention head
     unsigned seed;    // per-handle seed (tvc_sac_cfg.dropout_seed): different learners / ranks draw different mask sequences
+    unsigned zsplit;  // > 0: two forward calls batched in ONE launch -- groups z >= zsplit belong to the call whose site is site2 and are
+    unsigned site2;   //      its groups z - zsplit (the critics' loss: online nets = groups 0, 1, target nets = groups 2, 3); 0 = off
 };
 __device__ __forceinline__ unsigned drop_mix(unsigned x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
 __device__ __forceinline__ unsigned drop_key(const DropArgs& d, unsigned z) {
-    return drop_mix((unsigned)(*d.ctr) ^ (d.site * 0x9E3779B9u) ^ (z * 0x7F4A7C15u) ^ d.seed);
+    const bool second = d.zsplit != 0u && z >= d.zsplit;
+    const unsigned site = second ? d.site2 : d.site, zz = second ? z - d.zsplit : z;
+    return drop_mix((unsigned)(*d.ctr) ^ (site * 0x9E3779B9u) ^ (zz * 0x7F4A7C15u) ^ d.seed);
 }
 __device__ __forceinline__ float drop_factor(const DropArgs& d, unsigned key, int row, int col) {
     const unsigned c = (unsigned)col / (unsigned)d.group;
@@ -1165,6 +1169,7 @@ struct ThinArgs {
     const float* dZ; float* dW; float* dX;
     int M, N, K, K1, act;
     long gX, gX2, gW, gB, gY, gDW, gDX;  // group strides (blockIdx.z)
+    int gdiv;                            // > 1: the INPUT strides gX / gX2 apply to z / gdiv (two nets per input: thin_fwd_kernel only)
 };
 __device__ __forceinline__ float thin_x(const ThinArgs& a, const float* X, const float* X2, int row, int k) {
     // clamped address, zero-selected after the load (never a branch around a load)
@@ -1178,9 +1183,9 @@ __global__ void __launch_bounds__(256) thin_fwd_kernel(ThinArgs a) {
     TVC_LEARNER_PRIO();
     __shared__ float xs[THIN_ROWS][THIN_K];
     const int tid = threadIdx.x, n = blockIdx.y * 256 + tid, row0 = blockIdx.x * THIN_ROWS;
-    const long z = blockIdx.z;
-    const float* X = a.X + z * a.gX;
-    const float* X2 = a.X2 ? a.X2 + z * a.gX2 : nullptr;
+    const long z = blockIdx.z, zi = a.gdiv > 1 ? z / a.gdiv : z;
+    const float* X = a.X + zi * a.gX;
+    const float* X2 = a.X2 ? a.X2 + zi * a.gX2 : nullptr;
     if (tid < THIN_ROWS * THIN_K) xs[tid / THIN_K][tid % THIN_K] = thin_x(a, X, X2, row0 + tid / THIN_K, tid % THIN_K);
     const int nc = min(n, a.N - 1);
     const float* W = a.W + z * a.gW + (long)nc * a.K;

@@ -346,25 +346,27 @@ static void launch_gemm_bwd_pair(const GemmArgs& w, const GemmArgs& x, int G, hi
 }
 
 // optional second input source of a net whose first layer reads a concatenation [X[:, :K1] | X2[:, :in_dim-K1]]
-struct In2 { const float* X2; long gX2; int K1, ldx, ldx2; };
+struct In2 { const float* X2; long gX2; int K1, ldx, ldx2; int gdiv = 1; };  // gdiv > 1: input group = z / gdiv
 static ThinArgs thin_input(const Op& o, const float* X, long gX, const In2* in2, int M) {
     ThinArgs a{};
     if (o.src != 0) in2 = nullptr;  // only the net input can be a two-source concatenation
     a.X = X; a.gX = gX; a.K = o.in_dim; a.M = M; a.N = o.out_dim;
     a.K1 = in2 ? in2->K1 : o.in_dim; a.ldx = in2 ? in2->ldx : o.in_dim;
     a.X2 = in2 ? in2->X2 : nullptr; a.ldx2 = in2 ? in2->ldx2 : 0; a.gX2 = in2 ? in2->gX2 : 0;
+    a.gdiv = in2 ? in2->gdiv : 1;
     return a;
 }
 static bool thin_ok(const Op& o) { return o.type == OP_LINEAR && o.in_dim <= THIN_K && o.res < 0; }
 
 // train-mode dropout of one forward call (and of the backward that follows it): the counter, p, and the site base that
 // tells this call's masks from every other call's
-struct DropCtl { const int* ctr; unsigned thresh; float scale; unsigned site_base; unsigned seed; };
+struct DropCtl { const int* ctr; unsigned thresh; float scale; unsigned site_base; unsigned seed; unsigned zsplit = 0, site_base2 = 0; };
 static DropArgs drop_args(const DropCtl* dc, int op_index, int group) {
     DropArgs d{};
     if (dc && group > 0) {
         d.ctr = dc->ctr; d.site = dc->site_base + (unsigned)op_index; d.thresh = dc->thresh; d.scale = dc->scale; d.group = group;
         d.seed = dc->seed;
+        d.zsplit = dc->zsplit; d.site2 = dc->site_base2 + (unsigned)op_index;
     }
     return d;
 }
@@ -850,11 +852,16 @@ __global__ void __launch_bounds__(256) critic_dgrad_headgrad_kernel(const float*
 // (agent/...:236-285, reported only); the other workgroups stack xs2 = [s ; s'] for the single actor forward.
 __global__ void __launch_bounds__(256) update_prep_kernel(const float* __restrict__ s, const float* __restrict__ a,
                                                           const float* __restrict__ s2, float* __restrict__ losses,
-                                                          float* __restrict__ xs2, int M, int no, int na, float weight) {
+                                                          float* __restrict__ xs2, int M, int no, int na, float weight,
+                                                          float* __restrict__ acat) {
     if (blockIdx.x > 0) {
         const long n = (long)M * no;
         for (long i = (long)(blockIdx.x - 1) * 256 + threadIdx.x; i < 2 * n; i += (long)(gridDim.x - 1) * 256)
             xs2[i] = i < n ? s[i] : s2[i - n];
+        // the batch's actions in front of the slot the target actions a' ~ pi(s') are sampled into: [a ; a'] is the second input
+        // source of the ONE critic forward over (s, a) and (s', a') (tvc_sac_critic_grads)
+        if (acat)
+            for (long i = (long)(blockIdx.x - 1) * 256 + threadIdx.x; i < (long)M * na; i += (long)(gridDim.x - 1) * 256) acat[i] = a[i];
         return;
     }
     float e = 0.f;
@@ -948,6 +955,7 @@ struct tvc_sac {
     float *xs2 = nullptr;   // [2B, obs]: states and next states stacked for the single actor forward of an update
     bool actor_fwd_valid = false;
     bool grads_clean[2] = {false, false};  // critics, actor: zeroed by the Adam kernel since they were last written
+    float *acat = nullptr;  // [2, B, A]: the batch's actions, then a_tmp (sampled actions)
     float *pe = nullptr, *xcat = nullptr, *a_tmp = nullptr, *y = nullptr, *dq = nullptr, *ls_tmp = nullptr, *mean_tmp = nullptr;
     AdamClock* clk = nullptr;  // [2]: critics, actor
     // one-launch acting pass (tvc_actor_rows.h): packed weight-tile stream + vector section, rebuilt after every policy update
@@ -1286,7 +1294,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     const int B = cfg->batch_size, A = cfg->act_dim, NA = cfg->max_act_rows;
     int maxd = 0;
     for (size_t b = 1; b < h->actor.buf_dim.size(); ++b) maxd = std::max(maxd, h->actor.buf_dim[b]);
-    long bytes = ctx_bytes(h->actor, 2 * B, 1, true) + ctx_bytes(h->critic, B, 2, true) + 8L * NA * maxd * 4 + 2L * B * cfg->obs_dim * 4 + 512;
+    long bytes = ctx_bytes(h->actor, 2 * B, 1, true) + ctx_bytes(h->critic, B, 4, true) + 8L * NA * maxd * 4 + 2L * B * cfg->obs_dim * 4 + 512;
     bytes += (long)cfg->pe_rows * cfg->d_model * 4 + (long)B * (cfg->obs_dim + A) * 4 * 2 + (long)B * 64 + (1 << 16);
     bytes += 256L * (4 * (h->actor.buf_dim.size() + h->critic.buf_dim.size()) * 3 + 64);
     h->ov_floats = (long)std::max(1, h->fold.layers) * ((long)h->fold.d * h->fold.d + h->fold.d + 4) +
@@ -1348,7 +1356,7 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     (void)hipMemset(h->slab, 0, bytes);
     char* p = (char*)h->slab;
     ctx_alloc_train(h->actx, h->actor, 2 * B, 1, p);
-    ctx_alloc_train(h->cctx, h->critic, B, 2, p);
+    ctx_alloc_train(h->cctx, h->critic, B, 4, p);  // groups 0, 1 = the online critics (saved for the backward), 2, 3 = the targets
     if (ctx_alloc_infer(h->ictx, h->actor_inf, NA, p) != 0) {
         (void)hipFree(h->slab);
         delete h;
@@ -1361,7 +1369,8 @@ int tvc_sac_create(const tvc_sac_cfg* cfg, int32_t device, float* params, float*
     h->pe = (float*)carve(p, (long)cfg->pe_rows * cfg->d_model * 4);
     h->xcat = (float*)carve(p, (long)B * (cfg->obs_dim + A) * 4);
     h->xs2 = (float*)carve(p, 2L * B * cfg->obs_dim * 4);
-    h->a_tmp = (float*)carve(p, (long)B * A * 4);
+    h->acat = (float*)carve(p, 2L * B * A * 4);
+    h->a_tmp = h->acat + (long)B * A;
     h->ls_tmp = (float*)carve(p, (long)B * A * 4);
     h->mean_tmp = (float*)carve(p, (long)B * A * 4);
     h->y = (float*)carve(p, (long)B * 4);
@@ -1721,6 +1730,10 @@ static const DropCtl* drop_ctl(tvc_sac* h, DropCtl& dc, unsigned site_base) {
     return &dc;
 }
 
+static bool merge_critic_forwards() {  // TVC_MERGE_CRITICS=0: the target and the online critics' forward as two launches chains (A/B)
+    static const bool v = [] { const char* e = getenv("TVC_MERGE_CRITICS"); return !e || atoi(e) != 0; }();
+    return v;
+}
 static int check_batch_ptrs(const void* a, const void* b, const void* c) {
     if (!a || !b || !c) return tvc::set_error(TVC_EINVAL, "null batch pointer");
     return 0;
@@ -1740,8 +1753,9 @@ int tvc_sac_critic_grads(tvc_sac* h, const float* s, const float* a, const float
     // ONE actor forward over [s ; s'] (2B rows): the policy parameters do not change between the target pass on s'
     // (here) and the policy pass on s (tvc_sac_actor_grads), so the rows of s are computed -- and saved for the
     // backward -- now, and the positional-encoding table is indexed modulo its rows
+    const bool one_critic_pass = no + A <= THIN_K && merge_critic_forwards();
     hipLaunchKernelGGL(update_prep_kernel, dim3(1 + (2 * B * no + 255) / 256), dim3(256), 0, st, s, a, s2, losses, h->xs2, B, no, A,
-                       0.1f);
+                       0.1f, one_critic_pass ? h->acat : (float*)nullptr);
     DropCtl dca, dcq;
     net_forward(h->actor, h->P_actor(), 0, h->xs2, 0, 2 * B, 1, h->actx, true, pe, c.pe_rows, st, nullptr, nullptr,
                 drop_ctl(h, dca, 0));
@@ -1750,20 +1764,36 @@ int tvc_sac_critic_grads(tvc_sac* h, const float* s, const float* a, const float
     hipLaunchKernelGGL(sample_action_kernel, dim3((B * A + 255) / 256), dim3(256), 0, st, h->actx.Y.back() + (long)B * 2 * A,
                        eps_next, h->a_tmp, (float*)nullptr, (float*)nullptr, B, A, 0, Ticks{nullptr, 0.f, 0.f, nullptr});
     In2 in2;
-    const float* x = critic_input(h, s2, h->a_tmp, in2, st);
-    {   // the target critics' output goes to its own buffer: the online pass below reuses the context, and the loss kernel forms
-        // y = r + gamma (1 - d) min(tq1, tq2) itself
-        float* keep = h->cctx.Y.back();
-        h->cctx.Y.back() = h->tq;
-        net_forward(h->critic, h->P_tq(), h->n_critic, x, 0, B, 2, h->cctx, false, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr,
-                    drop_ctl(h, dcq, 120));
-        h->cctx.Y.back() = keep;
+    const float* x;
+    const float* tq = h->tq;
+    if (one_critic_pass) {
+        // ONE forward over four nets: groups 0, 1 = the online critics on (s, a) (saved for the backward), groups 2, 3 = the target
+        // critics on (s', a') -- the target parameters lie behind the online ones, the inputs are the halves of [s ; s'] and [a ; a']
+        // (input group = z / 2), the dropout sites stay those of the two separate calls (140 + op for z < 2, 120 + op and z - 2 behind)
+        In2 in4;
+        in4.X2 = h->acat; in4.gX2 = (long)B * A; in4.K1 = no; in4.ldx = no; in4.ldx2 = A; in4.gdiv = 2;
+        const DropCtl* dq = drop_ctl(h, dcq, 140);
+        if (dq) { dcq.zsplit = 2; dcq.site_base2 = 120; }
+        net_forward(h->critic, h->P_q(), h->n_critic, h->xs2, (long)B * no, B, 4, h->cctx, true, nullptr, 0, st, nullptr, &in4, dq);
+        tq = h->cctx.Y.back() + 2 * h->cctx.gY.back();
+        x = critic_input(h, s, a, in2, st);  // (what the backward reads: the same values as the first halves above)
+    } else {
+        x = critic_input(h, s2, h->a_tmp, in2, st);
+        {   // the target critics' output goes to its own buffer: the online pass below reuses the context, and the loss kernel forms
+            // y = r + gamma (1 - d) min(tq1, tq2) itself
+            float* keep = h->cctx.Y.back();
+            h->cctx.Y.back() = h->tq;
+            net_forward(h->critic, h->P_tq(), h->n_critic, x, 0, B, 2, h->cctx, false, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr,
+                        drop_ctl(h, dcq, 120));
+            h->cctx.Y.back() = keep;
+        }
+        // online critics on (s, a): forward (saved), loss, backward
+        x = critic_input(h, s, a, in2, st);
+        net_forward(h->critic, h->P_q(), h->n_critic, x, 0, B, 2, h->cctx, true, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr,
+                    drop_ctl(h, dcq, 140));
     }
-    // online critics on (s, a): forward (saved), loss, backward
-    x = critic_input(h, s, a, in2, st);
-    net_forward(h->critic, h->P_q(), h->n_critic, x, 0, B, 2, h->cctx, true, nullptr, 0, st, nullptr, in2.X2 ? &in2 : nullptr,
-                drop_ctl(h, dcq, 140));
-    hipLaunchKernelGGL(q_loss_kernel, dim3((B + 255) / 256, 2), dim3(256), 0, st, h->cctx.Y.back(), h->tq, r, d, c.gamma,
+    if (one_critic_pass && dcq.zsplit) { dcq.zsplit = 0; dcq.site_base2 = 0; }  // (the backward below regenerates the online nets' masks)
+    hipLaunchKernelGGL(q_loss_kernel, dim3((B + 255) / 256, 2), dim3(256), 0, st, h->cctx.Y.back(), tq, r, d, c.gamma,
                        h->cctx.dY.back(), losses, B);
     if (!h->grads_clean[0]) TVC_HIP_CHECK(hipMemsetAsync(h->G_q(), 0, 2 * h->n_critic * sizeof(float), st));
     h->grads_clean[0] = false;
