@@ -190,3 +190,25 @@ def test_segment_graphs_replay_the_loop_with_split_operand_acting():
     m_live = tr.sac.act(obs, None, x3=True)[1]
     assert torch.isfinite(m_live).all()
     tr.close()
+
+
+def test_hierarchical_acting_path_takes_the_split_operand_kernel():
+    """HierarchicalPolicy.act(x3=True): the goal-conditioned low-level policy (SqueezeExcitation block, 14-wide input) through
+    actor_x3_kernel -- same goals, actions within rounding of the f32 kernel's, also with the rows split into a CU-sharing and an
+    exclusive launch"""
+    from tvc_ai_amd.hierarchical import HierarchicalPolicy
+    n = 40000
+    hp = HierarchicalPolicy(10, 2, device="cuda:0", max_rows=n, seed=3)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    ob = torch.randn(n, 10, device="cuda", generator=g) * 0.5
+    ep, uu = torch.randn(n, 2, device="cuda", generator=g), torch.rand(n, device="cuda", generator=g)
+    a0, m0, l0, g0 = [t.clone() for t in hp.act(ob, ep, uu)]
+    a1, m1, l1, g1 = [t.clone() for t in hp.act(ob, ep, uu, x3=True)]
+    assert torch.equal(g0, g1)
+    d = max(float((m0 - m1).abs().max()), float((l0 - l1).abs().max()))
+    assert d <= 5e-5, d
+    a2, m2, l2, g2 = hp.act(ob, ep, uu, x3=True, share_rows=20000)
+    assert torch.equal(m2, m1) and torch.equal(a2, a1)
+    from tests import parity_log
+    parity_log.record("hierarchical_acting_x3", rows=n, max_abs_diff_vs_f32=d)
+    hp.close()
