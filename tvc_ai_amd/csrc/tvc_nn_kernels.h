@@ -1325,7 +1325,9 @@ __global__ void __launch_bounds__(256) fold_kernel(FoldArgs a, Ticks tk) {
         }
     }
 }
-// dW[n, k] = sum_m dZ[m, n] X[m, k]: 32 weight rows per workgroup, the 8 half-waves split the batch rows
+// dW[n, k] = sum_m dZ[m, n] X[m, k]: 32 weight rows per workgroup, the 8 half-waves split the batch rows; gridDim.y > 1: the batch
+// rows in gridDim.y slices of whole 64-row steps, summed with float atomics into a ZEROED dW (a 256-row batch was four dependent
+// load rounds on 8 - 16 workgroups: 8 - 9 us for 50 kFLOP)
 __global__ void __launch_bounds__(256) thin_wgrad_kernel(ThinArgs a) {
     TVC_LEARNER_PRIO();
     __shared__ float xs[64][THIN_K];
@@ -1339,7 +1341,9 @@ __global__ void __launch_bounds__(256) thin_wgrad_kernel(ThinArgs a) {
     float acc[THIN_K];
 #pragma unroll
     for (int k = 0; k < THIN_K; ++k) acc[k] = 0.0f;
-    for (int m0 = 0; m0 < a.M; m0 += 64) {
+    const int steps = (a.M + 63) / 64, per = (steps + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int m_lo = (int)blockIdx.y * per * 64, m_hi = min(a.M, m_lo + per * 64);
+    for (int m0 = m_lo; m0 < m_hi; m0 += 64) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1369,7 +1373,8 @@ __global__ void __launch_bounds__(256) thin_wgrad_kernel(ThinArgs a) {
         float s = 0.0f;
 #pragma unroll
         for (int g = 0; g < 8; ++g) s += red[g][nl][k];
-        dW[(long)(blockIdx.x * 32 + nl) * a.K + k] = s;
+        if (gridDim.y > 1) atomicAdd(dW + (long)(blockIdx.x * 32 + nl) * a.K + k, s);
+        else dW[(long)(blockIdx.x * 32 + nl) * a.K + k] = s;
     }
 }
 // dX[m, k] = sum_n dZ[m, n] W[n, k]: one wave per row
@@ -1605,6 +1610,9 @@ struct LnBwdArgs {
     float* dXm; DropArgs omask; // optional second output dX * mask: the dZ of a producing Linear whose (dropped) output was
                                 // added to a residual (dX itself stays unmasked for the residual path)
 };
+#ifndef LN_BWD_RPW
+#define LN_BWD_RPW 1   // rows per wave (4 waves per workgroup): 1 = 64 workgroups at batch 256 (update 517 -> 498 us; 2: 517, 4: 567)
+#endif
 template <int VPL>
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(LnBwdArgs a) {
     TVC_LEARNER_PRIO();
@@ -1619,8 +1627,8 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(LnBwdArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) { dg[i] = 0.f; db[i] = 0.f; cs[i] = 0.f; }
-    const int row_base = blockIdx.x * 8 + wave * 2;  // 2 rows per wave: short dependency chain, 32+ blocks at batch 256
-    for (int rr = 0; rr < 2; ++rr) {
+    const int row_base = blockIdx.x * (4 * LN_BWD_RPW) + wave * LN_BWD_RPW;  // one row per wave: the shortest dependency chain, 64+ workgroups at batch 256
+    for (int rr = 0; rr < LN_BWD_RPW; ++rr) {
         const int row = row_base + rr;
         if (row >= a.M) break;
         const long off = z * a.gA + (long)row * a.N;

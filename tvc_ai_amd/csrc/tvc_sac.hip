@@ -356,6 +356,10 @@ static ThinArgs thin_input(const Op& o, const float* X, long gX, const In2* in2,
     a.gdiv = in2 ? in2->gdiv : 1;
     return a;
 }
+static int thin_wgrad_slices(int M) {  // TVC_WGRAD_SLICES: batch slices of the thin layers' weight gradient (1 = no atomics)
+    static const int v = [] { const char* e = getenv("TVC_WGRAD_SLICES"); return e ? atoi(e) : 4; }();
+    return std::max(1, std::min(v, (M + 63) / 64));
+}
 static bool thin_ok(const Op& o) { return o.type == OP_LINEAR && o.in_dim <= THIN_K && o.res < 0; }
 
 // train-mode dropout of one forward call (and of the backward that follows it): the counter, p, and the site base that
@@ -669,7 +673,7 @@ static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, l
             }
             // gamma is read with the PARAMETER stride, dgamma written with the GRADIENT stride: both nets use the
             // same block layout, so the strides coincide whenever Gr != nullptr (gG == gP is asserted at create)
-            dim3 grid((M + 7) / 8, G), block(256);
+            dim3 grid((M + 4 * LN_BWD_RPW - 1) / (4 * LN_BWD_RPW), G), block(256);
             if (o.out_dim == 256) hipLaunchKernelGGL((layernorm_bwd_kernel<4>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((layernorm_bwd_kernel<8>), grid, block, 0, st, a);
         } else {  // LINEAR: c.dY[out] already holds dZ (act' and bias column sums were fused by its writer)
@@ -679,7 +683,8 @@ static void net_backward(const NetDef& nd, const float* P, long gP, float* Gr, l
                 a.dZ = dZ; a.gY = c.gY[out];
                 if (Gr) {
                     a.dW = Gr + o.w; a.gDW = gG;
-                    hipLaunchKernelGGL(thin_wgrad_kernel, dim3((o.out_dim + 31) / 32, 1, G), dim3(256), 0, st, a);
+                    // (the gradient buffer is zero here: tvc_sac_*_grads memset it or the Adam kernel left it zeroed)
+                    hipLaunchKernelGGL(thin_wgrad_kernel, dim3((o.out_dim + 31) / 32, thin_wgrad_slices(M), G), dim3(256), 0, st, a);
                 }
                 if (want_input_grad && hg && hg->A <= 2 && o.in_dim == hg->obs_dim + hg->A) {
                     hipLaunchKernelGGL(critic_dgrad_headgrad_kernel, dim3((M + 3) / 4), dim3(256), 0, st, dZ, c.gY[out], P + o.w, gP,
