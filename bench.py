@@ -404,6 +404,11 @@ def main():
         seg = tr.capture_segments()  # 4 graph launches + the 2 collectives per step instead of ~130 kernel launches
         step_fn = lambda k: seg()
         launch_mode = "segment graphs between the update's collectives (4 graph launches per step)"
+    if workload == "train" and use_graph and n >= 32768 and tr.overlap:
+        # the two streams' branches of ONE graph do not overlap at this size (3.8 ms per step at 32 768 envs against 1.10 eager,
+        # DESIGN.md 10.11): the whole-step graph is a small-shard mode; what is captured here is the sequential schedule
+        tr.overlap = False
+        launch_mode += ", sequential schedule (>= 32 768 envs)"
     dt, dev_us_per_step, captured = timed_steps(step_fn, K, W, world, device, use_graph)
 
     env_steps = float(n) * world * K
