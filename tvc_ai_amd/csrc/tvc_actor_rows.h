@@ -63,12 +63,6 @@ struct ArPipe {
     int wave;        // wave index in the workgroup, wave-uniform (readfirstlane): LDS destinations and M0 stay in SGPRs
     unsigned goff;   // this lane's byte offset inside a tile, (wave * 256 + lane) * 16: ONE 32-bit VGPR next to a scalar tile base
 };
-#ifndef AR_PARK
-#define AR_PARK 0   // head tiles parked in LDS (experiment)
-#endif
-#ifndef AR_PIN
-#define AR_PIN 0
-#endif
 #ifndef AR_NW
 #define AR_NW 4     // waves (16 rows each) per workgroup sharing one tile stream: 4 = 64 rows; 8 = 128 rows (experiment, profiles/r03_d_actor_rows.md)
 #endif
@@ -141,16 +135,14 @@ __device__ __forceinline__ void ar_frag2(float4 (&w)[2], const float4* __restric
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      \
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      \
     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0)
-// PARK0 >= 0: input tiles PARK0 .. are not in registers but parked in LDS (park[(kt - PARK0) * 64 * AR_NW], this thread's slot): the head
-template <int KT, int PARK0 = -1>
-__device__ __forceinline__ void ar_pass(ArPipe& p, const f32x4* __restrict__ x, f32x4* __restrict__ acc, int l15, int q,
-                                        const f32x4* park = nullptr) {
+template <int KT>
+__device__ __forceinline__ void ar_pass(ArPipe& p, const f32x4* __restrict__ x, f32x4* __restrict__ acc, int l15, int q) {
     float4 wa[2], wb[2];
     const float4* base = ar_next(p) + q * 256 + l15;
     ar_frag2(wa, base, 0);
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
-        const f32x4 xk = (PARK0 >= 0 && kt >= PARK0) ? park[(kt - PARK0) * 64 * AR_NW] : x[kt];
+        const f32x4 xk = x[kt];
 #pragma unroll
         for (int hp = 0; hp < 4; ++hp) {  // half-group pairs (2 hp, 2 hp + 1)
             ar_frag2(wb, base, 2 * hp + 1);
@@ -233,7 +225,7 @@ __device__ __forceinline__ void ar_layernorm(f32x4* __restrict__ u, const float*
 
 
 #ifndef AR_HEADPK
-#define AR_HEADPK 23  // packed fp32 + v_rcp_f32 in the epilogues. bit 0: GELU of the 512-wide head activation (146 -> 54 spilled registers, 1 725 -> 1 692 us at 65 536 rows); bit 1: its LayerNorm (no change); bit 2: GELU of the FFN (1 655 us); bit 3: GELU of the folded output head (569 spills: off); bit 4: the 256-wide LayerNorms (with bits 0-2: NO spilled register left, 1 629 us = 132 TFLOP/s, the CU-sharing form 991 -> 909 us per 32 768 rows)
+#define AR_HEADPK 23  // packed fp32 + v_rcp_f32 in the epilogues. bit 0: GELU of the 512-wide head activation (146 -> 54 spilled registers, 1 725 -> 1 692 us at 65 536 rows); bit 1: its LayerNorm (no change); bit 2: GELU of the FFN (1 655 us); bit 4: the 256-wide LayerNorms (with bits 0-2: NO spilled register left, 1 629 us = 132 TFLOP/s, the CU-sharing form 991 -> 909 us per 32 768 rows)
 #endif
 __device__ __forceinline__ f32x4 ar_splat(float c) { return (f32x4){c, c, c, c}; }
 // GELU of four values with packed fp32 instructions and the rational erf's quotient as p x rcp(q) (see fast_erff)
@@ -260,25 +252,6 @@ __device__ __forceinline__ f32x4 ar_gelu4(const f32x4 x) {
     const f32x4 e = z * p * rq;
     const f32x4 hx = x * 0.5f;
     return __builtin_elementwise_fma(hx, e, hx);
-}
-__device__ __forceinline__ float ar_gelu1(float x) {   // the same, one value
-    const float z = fminf(fmaxf(x * 0.7071067811865476f, -4.0f), 4.0f);
-    const float x2 = z * z;
-    float p = -2.72614225801306e-10f;
-    p = fmaf(p, x2, 2.77068142495902e-08f);
-    p = fmaf(p, x2, -2.10102402082508e-06f);
-    p = fmaf(p, x2, -5.69250639462346e-05f);
-    p = fmaf(p, x2, -7.34990630326855e-04f);
-    p = fmaf(p, x2, -2.95459980854025e-03f);
-    p = fmaf(p, x2, -1.60960333262415e-02f);
-    float q = -1.45660718464996e-05f;
-    q = fmaf(q, x2, -2.13374055278905e-04f);
-    q = fmaf(q, x2, -1.68282697438203e-03f);
-    q = fmaf(q, x2, -7.37332916720468e-03f);
-    q = fmaf(q, x2, -1.42647390514189e-02f);
-    const float e = z * p * __builtin_amdgcn_rcpf(q);
-    const float hx = 0.5f * x;
-    return fmaf(hx, e, hx);
 }
 template <int NT>
 __device__ __forceinline__ void ar_layernorm_pk(f32x4* __restrict__ u, const float* __restrict__ gamma, const float* __restrict__ beta, int q) {
@@ -314,12 +287,7 @@ __global__ void __launch_bounds__(256, 2) actor_rows_kernel(ActRowsArgs a) {
 #else
 __global__ void __launch_bounds__(64 * AR_NW) actor_rows_kernel(ActRowsArgs a) {
 #endif
-    __shared__ __attribute__((aligned(16))) float4 Bs[AR_NBUF * AR_TILE_F4];  // the 16 KB weight-tile buffers
-#if AR_PARK > 0
-    // ... and where the head parks the last AR_PARK tiles of its 512-wide activation while it is the B operand of policy_head.4
-    // (128 + 64 accumulators + fragments do not fit 256 registers: what hipcc spills goes to scratch = the Infinity Cache and back)
-    __shared__ __attribute__((aligned(16))) f32x4 Park[AR_PARK * 64 * AR_NW];
-#endif
+    __shared__ __attribute__((aligned(16))) float4 Bs[AR_NBUF * AR_TILE_F4];  // the ONLY LDS object: the 16 KB weight-tile buffers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, q = lane >> 4;
     const int row = blockIdx.x * (16 * AR_NW) + wave * 16 + l15;
     const int rowc = min(row, a.M - 1);
@@ -452,11 +420,6 @@ __global__ void __launch_bounds__(64 * AR_NW) actor_rows_kernel(ActRowsArgs a) {
 #else
     ar_layernorm<32>(pp, tv + 1024, tv + 1536, q); AR_T();
 #endif
-#if AR_PARK > 0
-    f32x4* park = Park + tid;
-#pragma unroll
-    for (int i = 0; i < AR_PARK; ++i) park[i * 64 * AR_NW] = pp[32 - AR_PARK + i];
-#endif
     // ---- 512 -> 512 GELU LayerNorm -> 2A outputs.  The LayerNorm and the output Linear are folded into running sums:
     //   out[o] = rstd (sum_n g_n gamma_n W[o,n] - mean sum_n gamma_n W[o,n]) + sum_n beta_n W[o,n] + b[o],  g = gelu(.)
     // (gamma_n W[o,n] and the two input-independent sums come ready-made from pack_head_kernel)
@@ -466,11 +429,7 @@ __global__ void __launch_bounds__(64 * AR_NW) actor_rows_kernel(ActRowsArgs a) {
     for (int half = 0; half < 2; ++half) {
         f32x4 a2[16];
         ar_zero<16>(a2);
-#if AR_PARK > 0
-        ar_pass<32, 32 - AR_PARK>(p, pp, a2, l15, q, park); AR_T();
-#else
         ar_pass<32>(p, pp, a2, l15, q); AR_T();
-#endif
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             const int tt = 16 * half + t;
@@ -480,26 +439,13 @@ __global__ void __launch_bounds__(64 * AR_NW) actor_rows_kernel(ActRowsArgs a) {
             for (int o = 0; o < 4; ++o) gw[o] = ar_vec4(tv + 3584 + 512 * o, tt, q);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#if AR_HEADPK & 8
-                const float v = ar_gelu1(a2[t][r] + b4[r]);
-#else
-                const float v = gelu_f(a2[t][r] + b4[r]);
-#endif
+                const float v = gelu_f(a2[t][r] + b4[r]);  // (IEEE division here: v_rcp_f32 in THIS epilogue tips the allocation over, 569 spills)
                 s1 += v;
                 s2 = fmaf(v, v, s2);
 #pragma unroll
                 for (int o = 0; o < 4; ++o) d[o] = fmaf(v, gw[o][r], d[o]);
             }
-#if AR_PIN
-            if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // (the vector loads of four tiles, not sixteen, in flight)
-#endif
         }
-#if AR_PIN
-        // the first half's epilogue must not sink into the second half's pass (hipcc moves it towards the use of its sums, behind that
-        // pass: 64 accumulators live beside the next 64, the hoisted vector loads spilled and reloaded behind a fresh tile copy)
-        asm volatile("" : "+v"(s1), "+v"(s2), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
-        __builtin_amdgcn_sched_barrier(0);
-#endif
     }
 #define AR_RED(v) v += __shfl_xor(v, 16); v += __shfl_xor(v, 32)
     AR_RED(s1); AR_RED(s2);
